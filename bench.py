@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""Headline benchmark: queries/s @ top-10 over a 1M x 384-d corpus (+ docs embedded/s).
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` (N > 1 is launched by
+``python -m torch.distributed.run``, one rank per GPU over RCCL) prints ONE JSON line on rank 0.
+
+Workload = BASELINE.json configs[1]:
+  search : corpus 1 000 000 x 384 fp32 unit rows (seed 1234) resident in HBM, row-sharded over
+           the N ranks; 10 000 queries (seed 4321) replicated; k = 10.  One *step* = all 10 000
+           queries answered: local exact scan -> (N > 1) all-gather of partial top-10 -> merge.
+           Fixed total work as N grows => "strong" scaling.
+  encode : e5-small-v2-shaped bf16 encoder, batch 512 x seq 256 synthetic token ids per rank
+           (timed separately in the same run once the encoder kernels are built).
+``value`` is queries/s of the search step (whole job); docs/s rides along in ``encode``.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+METRIC = "docs embedded/sec + queries/sec@top-10 (1M×384-d corpus), 1→8 MI355X"
+N_CORPUS = 1_000_000
+N_QUERIES = 10_000
+K = 10
+DIM = 384
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TF = 157.3   # fp32-input MFMA peak (= vector rate)
+
+
+class HipEvents:
+    """hipEvent pairs recorded by the C-ABI around the scan kernel on the launch stream."""
+
+    def __init__(self):
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+        self.hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        self.hip.hipEventSynchronize.argtypes = [C.c_void_p]
+
+    def create(self) -> C.c_void_p:
+        ev = C.c_void_p()
+        assert self.hip.hipEventCreate(C.byref(ev)) == 0
+        return ev
+
+    def elapsed_ms(self, a, b) -> float:
+        ms = C.c_float()
+        assert self.hip.hipEventSynchronize(b) == 0
+        assert self.hip.hipEventElapsedTime(C.byref(ms), a, b) == 0
+        return float(ms.value)
+
+
+def cpu_search_baseline(corpus_host: np.ndarray, queries_host: np.ndarray, k: int, budget_s: float = 20.0):
+    """The reference's CPU exact-search idiom on the box's host cores (kind "port"):
+    ``np.matmul(q, corpus.T)`` + top-k by argsort (scripts/simple_eval.py:25,35), chunked over
+    the corpus so the score matrix stays small.  Bounded sample: as many 100-query batches as
+    fit ~budget_s."""
+    from oracle import search as oracle  # checker / baseline leg only
+
+    done, t0 = 0, time.perf_counter()
+    batch = 100
+    while done < queries_host.shape[0]:
+        q = queries_host[done : done + batch]
+        best_s = np.full((q.shape[0], k), -np.inf, np.float32)
+        best_i = np.full((q.shape[0], k), -1, np.int64)
+        for lo in range(0, corpus_host.shape[0], 131072):
+            s = oracle.scores_blas(q, corpus_host[lo : lo + 131072])
+            part = np.argpartition(-s, k - 1, axis=1)[:, :k]
+            cand_s = np.concatenate([best_s, np.take_along_axis(s, part, axis=1)], axis=1)
+            cand_i = np.concatenate([best_i, part + lo], axis=1)
+            order = np.argsort(-cand_s, axis=1, kind="stable")[:, :k]
+            best_s = np.take_along_axis(cand_s, order, axis=1)
+            best_i = np.take_along_axis(cand_i, order, axis=1)
+        done += q.shape[0]
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return done / dt, done, dt
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--corpus", type=int, default=N_CORPUS)
+    ap.add_argument("--queries", type=int, default=N_QUERIES)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-encode", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import semantic_search_kd_amd as pkg
+    from semantic_search_kd_amd import _native
+    from semantic_search_kd_amd.dist import ShardedSearcher, shard_bounds
+
+    lib = _native.load()
+    n, nq = args.corpus, args.queries
+
+    # ---- synthetic inputs, generated on device ---------------------------
+    lo, hi = shard_bounds(n, world, rank)
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    shard_chunks = []
+    # every rank draws the same stream and keeps its rows, so the global corpus is independent of N
+    for c_lo in range(0, n, 1 << 18):
+        c_hi = min(c_lo + (1 << 18), n)
+        block = torch.randn((c_hi - c_lo, DIM), generator=gen, device=dev, dtype=torch.float32)
+        s_lo, s_hi = max(lo, c_lo), min(hi, c_hi)
+        if s_lo < s_hi:
+            shard_chunks.append(block[s_lo - c_lo : s_hi - c_lo].clone())
+        del block
+    shard = torch.cat(shard_chunks) if shard_chunks else torch.empty((0, DIM), device=dev)
+    del shard_chunks
+    shard /= shard.norm(dim=1, keepdim=True)
+    qgen = torch.Generator(device=dev).manual_seed(4321)
+    queries = torch.randn((nq, DIM), generator=qgen, device=dev, dtype=torch.float32)
+    queries /= queries.norm(dim=1, keepdim=True)
+
+    index = pkg.FAISSIndexBuilder(embedding_dim=DIM, index_type="HNSW", metric="ip", device=str(dev), id_offset=lo)
+    index.add(shard)
+    n_local = index.ntotal
+    searcher = ShardedSearcher(lambda q, k: index.search_device(q, k, normalize_queries=False))
+
+    # profiled variant of the local scan (events around the scan kernel, same stream)
+    ev = HipEvents()
+    ws_bytes = int(lib.sskd_index_search_workspace_bytes(n_local, nq, K))
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    out_s = torch.empty((nq, K), dtype=torch.float32, device=dev)
+    out_i = torch.empty((nq, K), dtype=torch.int64, device=dev)
+    ev_pairs = [(ev.create(), ev.create()) for _ in range(args.steps)]
+
+    def local_search_profiled(step):
+        a, b = ev_pairs[step]
+        _native.check(
+            lib.sskd_index_search_profiled(
+                index._tiled.data_ptr(), n_local, queries.data_ptr(), nq, K, lo,
+                out_s.data_ptr(), out_i.data_ptr(), ws.data_ptr(), ws.numel(),
+                int(torch.cuda.current_stream(dev).cuda_stream), a, b,
+            )
+        )
+        return out_s, out_i
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = searcher.search(queries, K)
+    barrier()
+    t0 = time.perf_counter()
+    for step in range(args.steps):
+        searcher.local_search = lambda q, k, _s=step: local_search_profiled(_s)
+        res = searcher.search(queries, K)
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    qps = nq * args.steps / dt
+
+    scan_ms = float(np.mean([ev.elapsed_ms(a, b) for a, b in ev_pairs]))
+    qpb, passes, slices, waves, scans = (C.c_int() for _ in range(5))
+    lib.sskd_index_search_plan(n_local, nq, K, qpb, passes, slices, waves, scans)
+    # algorithmic bytes of one scan launch: P passes x rows x 1536 B + queries + partial lists
+    alg_bytes = passes.value * n_local * DIM * 4 + nq * DIM * 4 + nq * K * 12
+    achieved_gbs = alg_bytes / (scan_ms * 1e-3) / 1e9
+    flops = 2.0 * nq * n_local * DIM
+    traffic = None
+    tpath = REPO / "profiles" / "scan_traffic.json"
+    if tpath.exists() and world == 1 and n == N_CORPUS and nq == N_QUERIES:
+        try:
+            traffic = json.loads(tpath.read_text()).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    line = {
+        "metric": METRIC,
+        "value": round(qps, 1),
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"cosine top-{K}: {nq} queries x {n} x {DIM}-d fp32 corpus in HBM (configs[1] search), "
+            f"row-sharded over {world} GPU(s), all-gather + merge",
+            "corpus_rows": n,
+            "queries": nq,
+            "k": K,
+            "queries_per_block": qpb.value,
+            "corpus_passes": passes.value,
+            "slices": slices.value,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "scan_topk_kernel",
+            "achieved": round(achieved_gbs, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
+            "traffic": traffic,
+            "kernel_ms": round(scan_ms, 4),
+            "algorithmic_bytes": alg_bytes,
+            "mfma_f32_tflops": round(flops / (scan_ms * 1e-3) / 1e12, 2),
+            "mfma_f32_frac": round(flops / (scan_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
+        },
+    }
+
+    # ---- encoder leg (docs embedded / s), once the kernels exist ---------------------------
+    if not args.no_encode:
+        try:
+            from semantic_search_kd_amd import bench_encode  # noqa: F401
+        except ImportError:
+            bench_encode = None
+        if bench_encode is not None:
+            line["encode"] = bench_encode(dev, world, args.steps, args.warmup, barrier)
+
+    # ---- CPU baseline: rank 0, N = 1 only --------------------------------------------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        corpus_host = shard.cpu().numpy()
+        queries_host = queries.cpu().numpy()
+        cpu_qps, cpu_nq, cpu_dt = cpu_search_baseline(corpus_host, queries_host, K)
+        threads = torch.get_num_threads()
+        try:
+            from threadpoolctl import threadpool_info
+
+            blas = [p["num_threads"] for p in threadpool_info() if p.get("user_api") == "blas"]
+            threads = max(blas) if blas else threads
+        except Exception:
+            pass
+        line["cpu_baseline"] = {
+            "value": round(cpu_qps, 2),
+            "unit": "queries/s",
+            "cores": threads,
+            "kind": "port",
+            "sample": f"{cpu_nq} of the {nq} queries against the full {n}-row corpus "
+            f"(numpy sgemm + argpartition, the reference's exact-search idiom), {cpu_dt:.1f} s",
+            "host_cpus": os.cpu_count(),
+        }
+        # parity spot check of what was just measured (first 100 queries, vs the same idiom)
+        from oracle import search as oracle
+
+        ref_s, ref_i = oracle.topk_blas(queries_host[:100], corpus_host, K)
+        got_s, got_i = res[0][:100].cpu().numpy(), res[1][:100].cpu().numpy()
+        ties = set(oracle.near_tie_queries(ref_s).tolist())
+        ok = all(np.array_equal(got_i[j], ref_i[j]) for j in range(100) if j not in ties)
+        line["parity"] = {
+            "checked_queries": 100,
+            "ids_identical": bool(ok),
+            "max_abs_score_diff": float(np.abs(got_s - ref_s).max()),
+            "near_tie_queries": len(ties),
+        }
+
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

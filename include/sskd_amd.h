@@ -1,0 +1,199 @@
+/*
+ * sskd_amd.h — C-ABI of the MI355X (gfx950) embedding-and-search path.
+ *
+ * This is the drop-in boundary for the hot path of Axionis47/semantic-search-kd:
+ * everything its `StudentModel` / `FAISSIndexBuilder` wrappers delegate to
+ * sentence-transformers and faiss-cpu is reachable through the entry points
+ * below.  The reference has no FFI of its own (it is 100 % Python); each entry
+ * point therefore cites the reference call site / third-party call it replaces
+ * (paths relative to the reference checkout).  INTEGRATION.md shows the ctypes
+ * stub a maintainer of the reference would add.
+ *
+ * Conventions (binding):
+ *   - plain `extern "C"`, no C++/torch types; pointers + sizes only
+ *   - every pointer named `d_*` is a DEVICE pointer (HBM) owned by the caller
+ *   - `stream` is a `hipStream_t` passed as `void*` (NULL = default stream);
+ *     all work is enqueued on it, nothing synchronises, nothing allocates
+ *   - every function returns 0 (SSKD_OK) or an SSKD_ERR_* code and never throws;
+ *     `sskd_last_error()` gives a thread-local message for the last failure
+ *   - scratch memory is caller-provided; `*_workspace_bytes()` sizes it
+ */
+#ifndef SSKD_AMD_H
+#define SSKD_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSKD_ABI_VERSION 1
+
+#define SSKD_OK 0
+#define SSKD_ERR_INVALID 1     /* bad argument (null pointer, bad shape, k < 1 ...) */
+#define SSKD_ERR_WORKSPACE 2   /* workspace too small */
+#define SSKD_ERR_HIP 3         /* a HIP runtime call / kernel launch failed */
+#define SSKD_ERR_UNSUPPORTED 4 /* shape outside what the gfx950 kernels are built for */
+
+/* Embedding width the kernels are specialised for (e5-small-v2: configs/kd.yaml:16,
+ * src/config.py:30, scripts/build_faiss_index.py:50). */
+#define SSKD_DIM 384
+/* Corpus rows per HBM tile (one 32x32x2 f32 MFMA M-block). */
+#define SSKD_TILE_ROWS 32
+/* Largest k served by ONE scan pass; larger k is served by chained passes. */
+#define SSKD_K_PASS 32
+/* Largest k accepted by sskd_index_search (schemas.py:12-16 caps k at 100 and
+ * rerank_top_k at 200). */
+#define SSKD_K_MAX 1024
+
+int sskd_abi_version(void);
+const char* sskd_last_error(void);
+/* Number of HIP devices visible, or -1; does not initialise a context. */
+int sskd_device_count(void);
+
+/* ------------------------------------------------------------------------- *
+ * Index storage ("add"):  replaces faiss.normalize_L2 + index.add()
+ *   reference: scripts/build_faiss_index.py:55-62 (build_from_parquet),
+ *              tests/conftest.py:184-185 (IndexFlatIP(384); index.add(x)),
+ *              configs/index.yaml:30 (normalize: true)
+ * The index lives in HBM as 32-row tiles laid out in MFMA-fragment order:
+ *   tile t, step u (0..47), lane l (0..63) holds row 32t + (l & 31),
+ *   columns 8u + 4(l >> 5) + {0,1,2,3}   -> 16 B per lane, 1 KiB per step,
+ *   48 KiB per tile; rows past n_rows in the last tile are zero.
+ * ------------------------------------------------------------------------- */
+int64_t sskd_index_padded_rows(int64_t n_rows);
+size_t sskd_index_tiled_bytes(int64_t n_rows);
+
+/* Copy `n_rows` row-major fp32 rows into the tiled index starting at index row
+ * `dst_row0` (must be a multiple of 32), optionally L2-normalising each row
+ * (x / ||x||_2, rows of zero norm left untouched: faiss.normalize_L2).
+ * The last partial tile written is zero-padded. */
+int sskd_index_add_rows(const float* d_rows, int64_t n_rows, int normalize,
+                        float* d_tiled, int64_t dst_row0, void* stream);
+
+/* Inverse of sskd_index_add_rows (for save(): faiss.write_index equivalent). */
+int sskd_index_get_rows(const float* d_tiled, int64_t row0, int64_t n_rows,
+                        float* d_rows, void* stream);
+
+/* In-place row L2 normalisation (faiss.normalize_L2 on a query batch). */
+int sskd_l2_normalize_rows(float* d_x, int64_t n_rows, int dim, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Exact inner-product top-k ("search"): replaces faiss index.search()
+ *   reference: src/serve/app.py:293-301 (index_builder.search(query_emb, k)),
+ *              src/kd/eval.py:86 (np.argsort(scores)[::-1][:k]),
+ *              tests/conftest.py:184 (IndexFlatIP)
+ * d_queries   : row-major fp32 [nq, 384]
+ * d_out_scores: fp32 [nq, k], descending; ties broken by lower id
+ * d_out_ids   : int64 [nq, k] = local row + id_offset; when fewer than k rows
+ *               exist the tail is (-FLT_MAX, -1) like faiss' heap neutral.
+ * Scores are the exact fp32 fma chain of the 32x32x2 f32 MFMA in the column
+ * order documented in DESIGN.md (oracle/csrc/oracle.c reproduces it bit for bit).
+ * ------------------------------------------------------------------------- */
+size_t sskd_index_search_workspace_bytes(int64_t n_rows, int nq, int k);
+int sskd_index_search(const float* d_tiled, int64_t n_rows,
+                      const float* d_queries, int nq, int k, int64_t id_offset,
+                      float* d_out_scores, int64_t* d_out_ids,
+                      void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* sskd_index_search with two optional hipEvent_t handles (as void*, may be NULL)
+ * recorded on `stream` immediately before and after the first scan kernel: lets a
+ * caller time the dominant kernel in-process (bench.py's roofline). */
+int sskd_index_search_profiled(const float* d_tiled, int64_t n_rows,
+                               const float* d_queries, int nq, int k, int64_t id_offset,
+                               float* d_out_scores, int64_t* d_out_ids,
+                               void* d_workspace, size_t workspace_bytes, void* stream,
+                               void* ev_scan_begin, void* ev_scan_end);
+
+/* Launch geometry the search would use (for roofline accounting in bench.py):
+ * queries per workgroup tile (B_q), corpus passes, slices, waves per workgroup,
+ * and scan passes needed for this k. Any out pointer may be NULL. */
+int sskd_index_search_plan(int64_t n_rows, int nq, int k, int* queries_per_block,
+                           int* corpus_passes, int* n_slices, int* waves_per_block,
+                           int* scan_passes);
+
+/* Merge `n_lists` per-shard top-k lists per query into one (the step after the
+ * RCCL all-gather; the reference has a single index, so no counterpart).
+ * d_scores fp32 [n_lists, nq, k_in], d_ids int64 [n_lists, nq, k_in] (global ids,
+ * -1 = empty). Output as sskd_index_search. */
+int sskd_topk_merge(const float* d_scores, const int64_t* d_ids, int n_lists, int nq,
+                    int k_in, int k_out, float* d_out_scores, int64_t* d_out_ids,
+                    void* stream);
+
+/* q @ d^T in fp32: replaces StudentModel.compute_similarity
+ *   reference: src/kd/eval.py:75, tests/test_student_model.py:104-124 */
+int sskd_similarity(const float* d_q, int nq, const float* d_d, int nd, int dim,
+                    float* d_out, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Encoder (e5-small-v2 shaped BERT): replaces SentenceTransformer.encode()'s
+ * Transformer -> Pooling(mean) -> Normalize modules
+ *   reference: tests/test_model_validation.py:80-89,256-262; configs/kd.yaml:16-19
+ * ------------------------------------------------------------------------- */
+
+/* Masked mean-pool + L2 normalise:
+ *   e = sum_t m_t h_t / max(sum_t m_t, 1e-9);  if normalize: e /= max(||e||, 1e-12)
+ * d_hidden: [B, S, 384] bf16 (hidden_is_bf16 = 1) or fp32 (0); d_mask int32 [B, S];
+ * d_out fp32 [B, 384] row-major. */
+int sskd_pool_normalize(const void* d_hidden, int hidden_is_bf16, const int32_t* d_mask,
+                        int B, int S, int normalize, float* d_out, void* stream);
+
+/* Architecture of the bi-encoder (src/config.py:22-32). */
+typedef struct sskd_encoder_config {
+  int32_t vocab_size;        /* 30522 */
+  int32_t hidden;            /* 384 (only value supported) */
+  int32_t layers;            /* 12 */
+  int32_t heads;             /* 12 (head dim 32, only value supported) */
+  int32_t intermediate;      /* 1536 (only value supported) */
+  int32_t max_positions;     /* 512 */
+  int32_t type_vocab;        /* 2 */
+  float layer_norm_eps;      /* 1e-12 */
+} sskd_encoder_config;
+
+/* Device weight table.  All matrices are bf16 row-major in the HF nn.Linear
+ * convention [out_features, in_features]; biases and LayerNorm parameters fp32. */
+typedef struct sskd_encoder_layer_weights {
+  const void* wqkv;   /* bf16 [1152, 384]  (Wq; Wk; Wv stacked) */
+  const float* bqkv;  /* [1152] */
+  const void* wo;     /* bf16 [384, 384] */
+  const float* bo;    /* [384] */
+  const float* ln1_g; /* [384] */
+  const float* ln1_b;
+  const void* w1;     /* bf16 [1536, 384] */
+  const float* b1;    /* [1536] */
+  const void* w2;     /* bf16 [384, 1536] */
+  const float* b2;    /* [384] */
+  const float* ln2_g;
+  const float* ln2_b;
+} sskd_encoder_layer_weights;
+
+typedef struct sskd_encoder_weights {
+  const void* word_emb;  /* bf16 [vocab, 384] */
+  const void* pos_emb;   /* bf16 [max_positions, 384] */
+  const void* type_emb;  /* bf16 [type_vocab, 384] (row 0 is used) */
+  const float* emb_ln_g; /* [384] */
+  const float* emb_ln_b;
+  const sskd_encoder_layer_weights* layers; /* HOST array of `layers` entries */
+} sskd_encoder_weights;
+
+size_t sskd_encoder_workspace_bytes(const sskd_encoder_config* cfg, int B, int S);
+
+/* Full forward: ids/mask int32 [B, S] -> L2-normalised (if normalize) fp32 [B, 384].
+ * bf16 activations and MFMA operands, fp32 accumulation / LayerNorm / softmax. */
+int sskd_encoder_forward(const sskd_encoder_config* cfg, const sskd_encoder_weights* w,
+                         const int32_t* d_ids, const int32_t* d_mask, int B, int S,
+                         int normalize, float* d_out, void* d_workspace,
+                         size_t workspace_bytes, void* stream);
+
+/* Same forward, stopping after the last encoder layer: bf16 [B, S, 384] hidden
+ * states (test hook for per-stage parity against the oracle). */
+int sskd_encoder_hidden(const sskd_encoder_config* cfg, const sskd_encoder_weights* w,
+                        const int32_t* d_ids, const int32_t* d_mask, int B, int S,
+                        void* d_hidden_bf16, void* d_workspace, size_t workspace_bytes,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSKD_AMD_H */

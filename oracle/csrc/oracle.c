@@ -1,0 +1,181 @@
+/*
+ * oracle.c — CPU restatement of the embedding-and-search hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library, and only as the checker.  The product path (semantic-search-kd_amd/)
+ * never links, imports or calls it.
+ *
+ * PARITY PINNING: the reference (Axionis47/semantic-search-kd) stores no golden
+ * vectors for this path, and its engines — faiss-cpu ^1.7.4,
+ * sentence-transformers ^2.2.2 (pyproject.toml:11-15) — are not installed here,
+ * so the search oracle is pinned by the reference's own *semantics* only:
+ *   - exact search idiom  top_k = np.argsort(scores)[::-1][:k]        src/kd/eval.py:86
+ *   - scores = q @ corpus.T in fp32                                    scripts/simple_eval.py:25
+ *   - faiss.IndexFlatIP(384).add / search on L2-normalised rows        tests/conftest.py:184-185
+ *   - ids int64, -1 when fewer than k rows                             src/serve/app.py:299-301
+ * "parity unpinned" for bit-level outputs; pinned for the encoder against
+ * transformers.BertModel (see oracle/encoder.py).
+ *
+ * Floating-point order.  fp32 dot products have no canonical summation order
+ * (BLAS, faiss and numpy all differ).  oracle_scores_fma() uses the order of the
+ * gfx950 kernel — the k-ordered fmaf chain of v_mfma_f32_32x32x2_f32 over the
+ * tiled column order — so GPU results can be compared BIT FOR BIT; the numpy
+ * restatement (oracle/search.py: q @ c.T through BLAS) gives the same scores
+ * within 1e-6 and is the cross-check for the <= 1e-3 tolerance of the north star.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define DIM_STEP 8
+
+/* One score in kernel order: for u in 0..dim/8: for e in 0..3:
+ *   acc = fma(c[8u+e],   q[8u+e],   acc)      (lane half h = 0, MFMA k = 0)
+ *   acc = fma(c[8u+4+e], q[8u+4+e], acc)      (lane half h = 1, MFMA k = 1)   */
+static inline float dot_fma_order(const float* c, const float* q, int dim) {
+  float acc = 0.0f;
+  for (int u = 0; u < dim / DIM_STEP; ++u) {
+    const float* cc = c + DIM_STEP * u;
+    const float* qq = q + DIM_STEP * u;
+    for (int e = 0; e < 4; ++e) {
+      acc = fmaf(cc[e], qq[e], acc);
+      acc = fmaf(cc[4 + e], qq[4 + e], acc);
+    }
+  }
+  return acc;
+}
+
+/* scores[nq, n] = Q C^T in kernel order (dim % 8 == 0). */
+void oracle_scores_fma(const float* q, int nq, const float* c, int64_t n, int dim, float* scores) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)nq; ++i)
+    for (int64_t r = 0; r < n; ++r)
+      scores[i * n + r] = dot_fma_order(c + r * dim, q + i * dim, dim);
+}
+
+/* rank order of the index: higher score first, then lower id (faiss and numpy
+ * leave ties unspecified; the build defines them — SURVEY.md §7). */
+static inline int ranks_before(float sa, int64_t ia, float sb, int64_t ib) {
+  return sa > sb || (sa == sb && ia < ib);
+}
+
+/* Insert (s, id) into a list sorted by rank order holding `len` of `k` entries. */
+static inline int topk_insert(float* ls, int64_t* li, int len, int k, float s, int64_t id) {
+  if (len == k && !ranks_before(s, id, ls[k - 1], li[k - 1])) return len;
+  int pos = len < k ? len : k - 1;
+  while (pos > 0 && ranks_before(s, id, ls[pos - 1], li[pos - 1])) {
+    ls[pos] = ls[pos - 1];
+    li[pos] = li[pos - 1];
+    --pos;
+  }
+  ls[pos] = s;
+  li[pos] = id;
+  return len < k ? len + 1 : k;
+}
+
+/* Exact top-k of every query over n rows (kernel-order scores): the semantics of
+ * faiss IndexFlatIP.search / np.argsort(scores)[::-1][:k].  Padding: (-FLT_MAX, -1)
+ * (faiss' CMin heap neutral, std::numeric_limits<float>::lowest()).  NaN scores
+ * are never selected. */
+void oracle_search_fma(const float* q, int nq, const float* c, int64_t n, int dim, int k,
+                       int64_t id_offset, float* out_scores, int64_t* out_ids) {
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int64_t i = 0; i < (int64_t)nq; ++i) {
+    float* ls = out_scores + i * k;
+    int64_t* li = out_ids + i * k;
+    int len = 0;
+    for (int64_t r = 0; r < n; ++r) {
+      const float s = dot_fma_order(c + r * dim, q + i * dim, dim);
+      if (s != s || s == -INFINITY) continue;
+      len = topk_insert(ls, li, len, k, s, r + id_offset);
+    }
+    for (int e = len; e < k; ++e) {
+      ls[e] = -3.402823466e+38f;
+      li[e] = -1;
+    }
+  }
+}
+
+/* Top-k of precomputed scores[nq, n] (any summation order), same rank rule. */
+void oracle_topk_of_scores(const float* scores, int nq, int64_t n, int k, int64_t id_offset,
+                           float* out_scores, int64_t* out_ids) {
+  for (int64_t i = 0; i < (int64_t)nq; ++i) {
+    float* ls = out_scores + i * k;
+    int64_t* li = out_ids + i * k;
+    int len = 0;
+    for (int64_t r = 0; r < n; ++r) {
+      const float s = scores[i * n + r];
+      if (s != s || s == -INFINITY) continue;
+      len = topk_insert(ls, li, len, k, s, r + id_offset);
+    }
+    for (int e = len; e < k; ++e) {
+      ls[e] = -3.402823466e+38f;
+      li[e] = -1;
+    }
+  }
+}
+
+/* Merge n_lists per-shard lists [n_lists, nq, k_in] (ids global, -1 = empty) into
+ * [nq, k_out]: the step after the all-gather of a row-sharded index. */
+void oracle_topk_merge(const float* scores, const int64_t* ids, int n_lists, int nq, int k_in,
+                       int k_out, float* out_scores, int64_t* out_ids) {
+  for (int64_t i = 0; i < (int64_t)nq; ++i) {
+    float* ls = out_scores + i * k_out;
+    int64_t* li = out_ids + i * k_out;
+    int len = 0;
+    for (int l = 0; l < n_lists; ++l)
+      for (int e = 0; e < k_in; ++e) {
+        const int64_t off = ((int64_t)l * nq + i) * k_in + e;
+        if (ids[off] < 0) continue;
+        len = topk_insert(ls, li, len, k_out, scores[off], ids[off]);
+      }
+    for (int e = len; e < k_out; ++e) {
+      ls[e] = -3.402823466e+38f;
+      li[e] = -1;
+    }
+  }
+}
+
+/* faiss.normalize_L2: x /= ||x||_2 per row, zero rows untouched. */
+void oracle_l2_normalize_rows(float* x, int64_t n, int dim) {
+  for (int64_t r = 0; r < n; ++r) {
+    float* p = x + r * dim;
+    double ss = 0.0;
+    for (int i = 0; i < dim; ++i) ss += (double)p[i] * p[i];
+    if (ss > 0.0) {
+      const float s = (float)(1.0 / sqrt(ss));
+      for (int i = 0; i < dim; ++i) p[i] *= s;
+    }
+  }
+}
+
+/* sentence_transformers Pooling(mean) + Normalize:
+ *   e = sum_t m_t h_t / max(sum_t m_t, 1e-9);  e /= max(||e||_2, 1e-12)
+ * hidden fp32 [B, S, H], mask int32 [B, S] -> out fp32 [B, H]. */
+void oracle_pool_normalize(const float* hidden, const int32_t* mask, int B, int S, int H,
+                           int normalize, float* out) {
+  double* acc = (double*)malloc(sizeof(double) * (size_t)H);
+  for (int b = 0; b < B; ++b) {
+    memset(acc, 0, sizeof(double) * (size_t)H);
+    double cnt = 0.0;
+    for (int t = 0; t < S; ++t) {
+      const int m = mask[(int64_t)b * S + t];
+      if (!m) continue;
+      cnt += m;
+      const float* h = hidden + ((int64_t)b * S + t) * H;
+      for (int i = 0; i < H; ++i) acc[i] += (double)m * h[i];
+    }
+    const double den = cnt > 1e-9 ? cnt : 1e-9;
+    double ss = 0.0;
+    for (int i = 0; i < H; ++i) {
+      acc[i] /= den;
+      ss += acc[i] * acc[i];
+    }
+    double nrm = sqrt(ss);
+    if (nrm < 1e-12) nrm = 1e-12;
+    for (int i = 0; i < H; ++i) out[(int64_t)b * H + i] = (float)(normalize ? acc[i] / nrm : acc[i]);
+  }
+  free(acc);
+}

@@ -1,0 +1,73 @@
+"""In-tree build of the gfx950 C-ABI library (``libsskd_amd.so``).
+
+``hipcc --offload-arch=gfx950`` cross-compiles without a GPU, so this runs in the
+CPU-only build container as well as on the MI355X box.  The shared object is
+written next to this file (git-ignored, but it travels with the repo snapshot).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+REPO_ROOT = PKG_DIR.parent
+CSRC = PKG_DIR / "csrc"
+INCLUDE = REPO_ROOT / "include"
+OBJ_DIR = PKG_DIR / "build"
+LIB_PATH = PKG_DIR / "libsskd_amd.so"
+
+SOURCES = ["capi_common.hip", "search.hip", "pool.hip", "encoder.hip"]
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950",
+    "-O3",
+    "-std=c++17",
+    "-fPIC",
+    "-Wno-unused-result",
+    "-Wno-unused-value",
+]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(exe).exists():
+        raise RuntimeError("hipcc not found: the MI355X backend needs the ROCm toolchain to build")
+    return exe
+
+
+def _newer(target: Path, deps) -> bool:
+    if not target.exists():
+        return False
+    t = target.stat().st_mtime
+    return all(t >= Path(d).stat().st_mtime for d in deps)
+
+
+def build_native(force: bool = False, verbose: bool = False) -> Path:
+    """Compile every HIP translation unit for gfx950 and link the C-ABI library."""
+    OBJ_DIR.mkdir(exist_ok=True)
+    headers = list(CSRC.glob("*.h")) + list(INCLUDE.glob("*.h"))
+    objs = []
+    rebuilt = False
+    for name in SOURCES:
+        src = CSRC / name
+        if not src.exists():
+            raise RuntimeError(f"missing source {src}")
+        obj = OBJ_DIR / (src.stem + ".o")
+        if force or not _newer(obj, [src, *headers]):
+            cmd = [_hipcc(), *HIPCC_FLAGS, f"-I{INCLUDE}", f"-I{CSRC}", "-c", str(src), "-o", str(obj)]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+            rebuilt = True
+        objs.append(obj)
+    if rebuilt or force or not _newer(LIB_PATH, objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB_PATH), *map(str, objs)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_native(force="--force" in os.sys.argv, verbose=True))

@@ -1,0 +1,695 @@
+// Exact inner-product top-k over a tiled fp32 corpus in HBM (gfx950 / MI355X).
+//
+// Replaces faiss `index.add` / `index.search` behind the reference's
+// FAISSIndexBuilder (reference: src/serve/app.py:293-301,
+// scripts/build_faiss_index.py:49-62, tests/conftest.py:184-185) and the
+// exact-search idiom `np.argsort(scores)[::-1][:k]` (src/kd/eval.py:86).
+//
+// Data layout (see include/sskd_amd.h): 32-row tiles, each stored as 48 steps
+// of 1 KiB in exactly the order the 64 lanes of a wave consume them as the A
+// operand of v_mfma_f32_32x32x2_f32, so every wave-instruction of the scan is
+// one contiguous 1 KiB read.
+//
+// Scan kernel: one workgroup = one block of 32*QB queries (held in LDS in
+// B-operand order) x one slice of corpus tiles.  Each wave streams its own
+// tiles HBM -> VGPR (software-pipelined 8 KiB ahead), feeds the fp32 MFMA, and
+// keeps a per-lane sorted top-K list in registers (lane j / j+32 own query j).
+// The lists of all waves / slices are merged by merge_topk_kernel.
+#include "common.h"
+
+#include <cfloat>
+#include <cstdlib>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int DIM = SSKD_DIM;                 // 384
+constexpr int TILE_ROWS = SSKD_TILE_ROWS;     // 32
+constexpr int STEPS = DIM / 8;                // 48 k-steps, 8 columns each
+constexpr int CHUNKS = DIM / 4;               // 96 float4 chunks per row
+constexpr int TILE_FLOATS = TILE_ROWS * DIM;  // 12288 floats = 48 KiB
+constexpr int GROUP = 8;                      // k-steps per prefetch group
+constexpr int GROUPS = STEPS / GROUP;         // 6 (even: groups alternate A/B)
+constexpr int STEP_FLOATS = 64 * 4;           // one wave-instruction: 1 KiB
+
+// ------------------------------------------------------------------------- //
+// index add / get / normalise
+// ------------------------------------------------------------------------- //
+
+// sum of squares of one row held as 96 float4 over the lanes of one wave
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// One workgroup per tile. Rows go global(row-major) -> LDS -> global(tiled).
+__global__ __launch_bounds__(256) void index_add_rows_kernel(
+    const float4* __restrict__ rows, int64_t n_rows, int normalize, float4* __restrict__ tiled,
+    int64_t dst_tile0) {
+  __shared__ float4 lds[TILE_ROWS * (CHUNKS + 1)];
+  __shared__ float inv_norm[TILE_ROWS];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int64_t row0 = (int64_t)blockIdx.x * TILE_ROWS;
+
+  // each wave owns 8 rows: coalesced float4 reads, norm by wave reduction
+  for (int rr = 0; rr < 8; ++rr) {
+    const int r = wave * 8 + rr;
+    const int64_t row = row0 + r;
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    if (row < n_rows) {
+      v0 = rows[row * CHUNKS + lane];
+      if (lane < CHUNKS - 64) v1 = rows[row * CHUNKS + 64 + lane];
+    }
+    float ss = v0.x * v0.x + v0.y * v0.y + v0.z * v0.z + v0.w * v0.w;
+    ss += v1.x * v1.x + v1.y * v1.y + v1.z * v1.z + v1.w * v1.w;
+    ss = wave_sum(ss);
+    lds[r * (CHUNKS + 1) + lane] = v0;
+    if (lane < CHUNKS - 64) lds[r * (CHUNKS + 1) + 64 + lane] = v1;
+    if (lane == 0) inv_norm[r] = (normalize && ss > 0.f) ? 1.0f / sqrtf(ss) : 1.0f;
+  }
+  __syncthreads();
+  float4* out = tiled + (dst_tile0 + blockIdx.x) * (int64_t)(TILE_ROWS * CHUNKS);
+  for (int idx = tid; idx < TILE_ROWS * CHUNKS; idx += 256) {
+    const int c = idx >> 5, r = idx & 31;  // tiled order: chunk-major, row-minor
+    float4 v = lds[r * (CHUNKS + 1) + c];
+    const float s = inv_norm[r];
+    v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+    out[idx] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void index_get_rows_kernel(const float4* __restrict__ tiled,
+                                                             int64_t row0, int64_t n_rows,
+                                                             float4* __restrict__ rows) {
+  const int64_t total = n_rows * CHUNKS;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * 256) {
+    const int64_t r = idx / CHUNKS;
+    const int c = (int)(idx - r * CHUNKS);
+    const int64_t row = row0 + r;
+    rows[idx] = tiled[(row >> 5) * (int64_t)(TILE_ROWS * CHUNKS) + c * 32 + (row & 31)];
+  }
+}
+
+// one wave per row, any dim; x / ||x|| (faiss.normalize_L2: zero rows untouched)
+__global__ __launch_bounds__(256) void l2_normalize_rows_kernel(float* __restrict__ x,
+                                                               int64_t n_rows, int dim) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  float* p = x + row * dim;
+  float ss = 0.f;
+  for (int i = lane; i < dim; i += 64) ss += p[i] * p[i];
+  ss = wave_sum(ss);
+  if (ss > 0.f) {
+    const float s = 1.0f / sqrtf(ss);
+    for (int i = lane; i < dim; i += 64) p[i] *= s;
+  }
+}
+
+// ------------------------------------------------------------------------- //
+// scan
+// ------------------------------------------------------------------------- //
+
+struct ScanParams {
+  const float* tiled;
+  const float* queries;
+  float* part_scores;    // [nq][lists_per_query][K]
+  int* part_ids;
+  const float* ub_scores;  // chained pass: exclusive upper bound per query
+  const int* ub_ids;
+  int64_t n_rows;
+  int n_tiles;
+  int nq;
+  int n_slices;
+  int tiles_per_slice;
+  int lists_per_query;
+};
+
+// strict "a ranks before b": higher score first, then lower id
+__device__ inline bool ranks_before(float sa, int ia, float sb, int ib) {
+  return sa > sb || (sa == sb && ia < ib);
+}
+
+template <int K>
+struct LaneList {
+  float s[K];
+  int id[K];
+  __device__ inline void clear() {
+#pragma unroll
+    for (int i = 0; i < K; ++i) { s[i] = -INFINITY; id[i] = -1; }
+  }
+  // precondition: x > s[K-1]. Rows reach a lane in increasing id order, so a
+  // strict compare keeps the lower id ahead among equal scores.
+  __device__ inline void insert(float x, int xid) {
+    s[K - 1] = x;
+    id[K - 1] = xid;
+#pragma unroll
+    for (int i = K - 1; i > 0; --i) {
+      const bool sw = s[i] > s[i - 1];
+      const float a = s[i - 1], b = s[i];
+      const int ia = id[i - 1], ib = id[i];
+      s[i - 1] = sw ? b : a;
+      s[i] = sw ? a : b;
+      id[i - 1] = sw ? ib : ia;
+      id[i] = sw ? ia : ib;
+    }
+  }
+};
+
+__device__ inline void load_group(float4 (&buf)[GROUP], const float* __restrict__ base) {
+#pragma unroll
+  for (int s = 0; s < GROUP; ++s)
+    buf[s] = *reinterpret_cast<const float4*>(base + s * STEP_FLOATS);
+}
+
+template <int QB, int G>
+__device__ inline void compute_group(const float4 (&a)[GROUP], const float4* __restrict__ qlane,
+                                     f32x16 (&acc)[QB]) {
+  // compiler-only barrier: keeps the (tile-invariant) LDS query reads inside the
+  // group instead of hoisted out of the tile loop into 192 VGPRs
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int s = 0; s < GROUP; ++s) {
+    const int u = G * GROUP + s;
+#pragma unroll
+    for (int qq = 0; qq < QB; ++qq) {
+      // chunk 2u + h of query j of sub-block qq (h, j folded into qlane)
+      const float4 b = qlane[(qq * CHUNKS + 2 * u) * 32];
+      acc[qq] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].x, b.x, acc[qq], 0, 0, 0);
+      acc[qq] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].y, b.y, acc[qq], 0, 0, 0);
+      acc[qq] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].z, b.z, acc[qq], 0, 0, 0);
+      acc[qq] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].w, b.w, acc[qq], 0, 0, 0);
+    }
+  }
+}
+
+template <int K, int QB, int WAVES, bool HAS_UB>
+__global__ __launch_bounds__(WAVES * 64) void scan_topk_kernel(ScanParams p) {
+  extern __shared__ float4 qs[];  // [QB][96 chunks][32 queries]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int slice = blockIdx.x % p.n_slices;  // blocks b, b+8 share an XCD: a slice stays on one L2
+  const int qblk = blockIdx.x / p.n_slices;
+  const int q0 = qblk * (32 * QB);
+
+  // stage the query block in B-operand order (zero rows past nq)
+  for (int idx = tid; idx < QB * 32 * CHUNKS; idx += WAVES * 64) {
+    const int c = idx % CHUNKS, jj = idx / CHUNKS;
+    const int q = q0 + jj;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < p.nq) v = reinterpret_cast<const float4*>(p.queries)[(int64_t)q * CHUNKS + c];
+    qs[((jj >> 5) * CHUNKS + c) * 32 + (jj & 31)] = v;
+  }
+  __syncthreads();
+  const float4* qlane = qs + h * 32 + j;
+
+  LaneList<K> list[QB];
+  float ub_s[QB];
+  int ub_i[QB];
+#pragma unroll
+  for (int qq = 0; qq < QB; ++qq) {
+    list[qq].clear();
+    ub_s[qq] = INFINITY;
+    ub_i[qq] = -1;
+    if (HAS_UB) {
+      const int q = q0 + qq * 32 + j;
+      if (q < p.nq) { ub_s[qq] = p.ub_scores[q]; ub_i[qq] = p.ub_ids[q]; }
+    }
+  }
+
+  const int t_begin = slice * p.tiles_per_slice;
+  const int t_end = min(t_begin + p.tiles_per_slice, p.n_tiles);
+  const float* lane_base = p.tiled + lane * 4;
+  const bool ragged = (p.n_rows & 31) != 0;
+
+  float4 bufA[GROUP], bufB[GROUP];
+  int t = t_begin + wave;
+  if (t < t_end) load_group(bufA, lane_base + (int64_t)t * TILE_FLOATS);
+
+  for (; t < t_end; t += WAVES) {
+    const float* tile = lane_base + (int64_t)t * TILE_FLOATS;
+    f32x16 acc[QB];
+#pragma unroll
+    for (int qq = 0; qq < QB; ++qq)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[qq][r] = 0.f;
+
+    load_group(bufB, tile + 1 * GROUP * STEP_FLOATS);
+    compute_group<QB, 0>(bufA, qlane, acc);
+    load_group(bufA, tile + 2 * GROUP * STEP_FLOATS);
+    compute_group<QB, 1>(bufB, qlane, acc);
+    load_group(bufB, tile + 3 * GROUP * STEP_FLOATS);
+    compute_group<QB, 2>(bufA, qlane, acc);
+    load_group(bufA, tile + 4 * GROUP * STEP_FLOATS);
+    compute_group<QB, 3>(bufB, qlane, acc);
+    load_group(bufB, tile + 5 * GROUP * STEP_FLOATS);
+    compute_group<QB, 4>(bufA, qlane, acc);
+    if (t + WAVES < t_end) load_group(bufA, tile + (int64_t)WAVES * TILE_FLOATS);
+    compute_group<QB, 5>(bufB, qlane, acc);
+
+    // D layout of the 32x32 MFMA: column = lane & 31 (query), row = (r&3) + 8(r>>2) + 4h
+    const int rowbase = t * TILE_ROWS + 4 * h;
+    if (ragged && t == p.n_tiles - 1) {
+#pragma unroll
+      for (int qq = 0; qq < QB; ++qq)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (rowbase + (r & 3) + 8 * (r >> 2) >= p.n_rows) acc[qq][r] = -INFINITY;
+    }
+#pragma unroll
+    for (int qq = 0; qq < QB; ++qq) {
+      float m = acc[qq][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[qq][r]);
+      if (__any(m > list[qq].s[K - 1])) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float x = acc[qq][r];
+          const int xid = rowbase + (r & 3) + 8 * (r >> 2);
+          bool take = x > list[qq].s[K - 1];
+          if (HAS_UB) take = take && ranks_before(ub_s[qq], ub_i[qq], x, xid);
+          if (__any(take)) {
+            if (take) list[qq].insert(x, xid);
+          }
+        }
+      }
+    }
+  }
+
+  // per-lane lists -> global partials [q][slice, wave, h][K]
+#pragma unroll
+  for (int qq = 0; qq < QB; ++qq) {
+    const int q = q0 + qq * 32 + j;
+    if (q < p.nq) {
+      const int64_t base =
+          ((int64_t)q * p.lists_per_query + (slice * WAVES + wave) * 2 + h) * K;
+#pragma unroll
+      for (int i = 0; i < K; ++i) {
+        p.part_scores[base + i] = list[qq].s[i];
+        p.part_ids[base + i] = list[qq].id[i];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------- //
+// merge: one wave per query, `count` rounds of bounded arg-best
+// ------------------------------------------------------------------------- //
+
+template <typename IdT>
+struct MergeParams {
+  const float* scores;
+  const IdT* ids;
+  int64_t list_stride;  // elements between consecutive lists of one query
+  int64_t q_stride;     // elements between consecutive queries
+  int k_in;             // entries per list
+  int n_cand;           // n_lists * k_in
+  int nq;
+  float* out_scores;    // [nq][out_stride], written at [out_off, out_off + count)
+  int64_t* out_ids;
+  int out_stride;
+  int out_off;
+  int count;
+  int64_t id_offset;
+  float* ub_scores;     // optional: last selected (score, local id) per query
+  int* ub_ids;
+};
+
+template <typename IdT>
+__global__ __launch_bounds__(256) void merge_topk_kernel(MergeParams<IdT> p) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= p.nq) return;
+  const float* sc = p.scores + (int64_t)q * p.q_stride;
+  const IdT* id = p.ids + (int64_t)q * p.q_stride;
+
+  float bs = INFINITY;  // bound: last selected entry
+  long long bi = -1;
+  bool have_bound = false;
+  float last_s = -INFINITY;
+  long long last_i = -1;
+  for (int r = 0; r < p.count; ++r) {
+    float best_s = -INFINITY;
+    long long best_i = -1;
+    for (int c = lane; c < p.n_cand; c += 64) {
+      const int l = c / p.k_in, e = c - l * p.k_in;
+      const int64_t off = (int64_t)l * p.list_stride + e;
+      const long long ci = (long long)id[off];
+      if (ci < 0) continue;
+      const float cs = sc[off];
+      // strictly after the bound in rank order
+      if (have_bound && !(cs < bs || (cs == bs && ci > bi))) continue;
+      if (best_i < 0 || cs > best_s || (cs == best_s && ci < best_i)) { best_s = cs; best_i = ci; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float os = __shfl_xor(best_s, o);
+      const long long oi = __shfl_xor(best_i, o);
+      if (oi >= 0 && (best_i < 0 || os > best_s || (os == best_s && oi < best_i))) {
+        best_s = os;
+        best_i = oi;
+      }
+    }
+    if (lane == 0) {
+      const int64_t o = (int64_t)q * p.out_stride + p.out_off + r;
+      p.out_scores[o] = best_i >= 0 ? best_s : -FLT_MAX;
+      p.out_ids[o] = best_i >= 0 ? (int64_t)best_i + p.id_offset : -1;
+    }
+    if (best_i < 0) {
+      // exhausted: fill the rest and stop
+      if (lane == 0) {
+        for (int rr = r + 1; rr < p.count; ++rr) {
+          const int64_t o = (int64_t)q * p.out_stride + p.out_off + rr;
+          p.out_scores[o] = -FLT_MAX;
+          p.out_ids[o] = -1;
+        }
+      }
+      last_s = -INFINITY;
+      last_i = 0x7fffffff;  // nothing ranks after this bound
+      break;
+    }
+    bs = best_s;
+    bi = best_i;
+    have_bound = true;
+    last_s = best_s;
+    last_i = best_i;
+  }
+  if (p.ub_scores && lane == 0) {
+    p.ub_scores[q] = last_s;
+    p.ub_ids[q] = (int)last_i;
+  }
+}
+
+__global__ __launch_bounds__(256) void fill_empty_kernel(float* s, int64_t* ids, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { s[i] = -FLT_MAX; ids[i] = -1; }
+}
+
+// ------------------------------------------------------------------------- //
+// similarity: out[nq, nd] = q d^T, same fma order as the scan
+// ------------------------------------------------------------------------- //
+
+// one wave per 32 (d rows) x 32 (q rows) output block; generic dim % 8 == 0
+__global__ __launch_bounds__(64) void similarity_kernel(const float* __restrict__ q, int nq,
+                                                        const float* __restrict__ d, int nd,
+                                                        int dim, float* __restrict__ out) {
+  const int lane = threadIdx.x;
+  const int j = lane & 31, h = lane >> 5;
+  const int d0 = blockIdx.x * 32, q0 = blockIdx.y * 32;
+  const int drow = min(d0 + j, nd - 1), qrow = min(q0 + j, nq - 1);
+  const float4* dp = reinterpret_cast<const float4*>(d + (int64_t)drow * dim) + h;
+  const float4* qp = reinterpret_cast<const float4*>(q + (int64_t)qrow * dim) + h;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int u = 0; u < dim / 8; ++u) {
+    const float4 a = dp[2 * u], b = qp[2 * u];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+  }
+  const int qi = q0 + j;
+  if (qi < nq) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int di = d0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (di < nd) out[(int64_t)qi * nd + di] = acc[r];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------- //
+// launch plan
+// ------------------------------------------------------------------------- //
+
+struct Plan {
+  int K;          // per-lane list length (template)
+  int QB;         // 32-query sub-blocks per workgroup
+  int waves;      // waves per workgroup
+  int n_qblocks;
+  int n_slices;
+  int tiles_per_slice;
+  int n_tiles;
+  int lists_per_query;
+  int passes;     // scan passes (k > SSKD_K_PASS is served by chaining)
+  size_t part_elems;
+};
+
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+Plan make_plan(int64_t n_rows, int nq, int k) {
+  Plan pl{};
+  pl.n_tiles = (int)sskd::ceil_div(n_rows, TILE_ROWS);
+  const int kk = k < SSKD_K_PASS ? k : SSKD_K_PASS;
+  pl.K = kk <= 10 ? 10 : (kk <= 16 ? 16 : 32);
+  pl.passes = (int)sskd::ceil_div(k, SSKD_K_PASS);
+  pl.waves = 8;
+  int qb = nq > 32 ? 2 : 1;
+  const int qb_env = env_int("SSKD_SCAN_QB", 0);
+  if (qb_env == 1 || qb_env == 2) qb = qb_env;
+  if (pl.K == 32) qb = 1;  // register budget: 2 x 64 list registers do not fit 2 waves/SIMD
+  pl.QB = qb;
+  pl.n_qblocks = (int)sskd::ceil_div(nq, 32 * qb);
+  // enough workgroups to fill 256 CUs several times over; slices in multiples
+  // of 8 so that blockIdx % 8 (the XCD label) is a function of the slice
+  const int target_wgs = env_int("SSKD_SCAN_TARGET_WGS", 1024);
+  int slices = (int)sskd::ceil_div(target_wgs, pl.n_qblocks);
+  slices = (int)sskd::ceil_div(slices, 8) * 8;
+  const int max_slices = (int)sskd::ceil_div(pl.n_tiles, pl.waves);  // >= 1 tile per wave
+  if (slices > max_slices) slices = max_slices;
+  if (slices < 1) slices = 1;
+  pl.tiles_per_slice = (int)sskd::ceil_div(pl.n_tiles > 0 ? pl.n_tiles : 1, slices);
+  pl.n_slices = (int)sskd::ceil_div(pl.n_tiles > 0 ? pl.n_tiles : 1, pl.tiles_per_slice);
+  pl.lists_per_query = pl.n_slices * pl.waves * 2;
+  pl.part_elems = (size_t)nq * pl.lists_per_query * pl.K;
+  return pl;
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+template <int K, int QB, bool HAS_UB>
+void launch_scan(const Plan& pl, const ScanParams& sp, hipStream_t st) {
+  constexpr int WAVES = 8;
+  const size_t lds = (size_t)QB * 32 * CHUNKS * sizeof(float4);
+  auto kern = scan_topk_kernel<K, QB, WAVES, HAS_UB>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3(pl.n_qblocks * pl.n_slices), dim3(WAVES * 64), lds, st, sp);
+}
+
+template <bool HAS_UB>
+int dispatch_scan(const Plan& pl, const ScanParams& sp, hipStream_t st) {
+  if (pl.K == 10 && pl.QB == 1) launch_scan<10, 1, HAS_UB>(pl, sp, st);
+  else if (pl.K == 10 && pl.QB == 2) launch_scan<10, 2, HAS_UB>(pl, sp, st);
+  else if (pl.K == 16 && pl.QB == 1) launch_scan<16, 1, HAS_UB>(pl, sp, st);
+  else if (pl.K == 16 && pl.QB == 2) launch_scan<16, 2, HAS_UB>(pl, sp, st);
+  else if (pl.K == 32 && pl.QB == 1) launch_scan<32, 1, HAS_UB>(pl, sp, st);
+  else return sskd::fail(SSKD_ERR_UNSUPPORTED, "no scan kernel for K=%d QB=%d", pl.K, pl.QB);
+  return sskd::check_launch("scan_topk_kernel");
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------- //
+// C-ABI
+// ------------------------------------------------------------------------- //
+
+extern "C" {
+
+int64_t sskd_index_padded_rows(int64_t n_rows) {
+  return n_rows <= 0 ? 0 : sskd::ceil_div(n_rows, TILE_ROWS) * TILE_ROWS;
+}
+
+size_t sskd_index_tiled_bytes(int64_t n_rows) {
+  return (size_t)sskd_index_padded_rows(n_rows) * DIM * sizeof(float);
+}
+
+int sskd_index_add_rows(const float* d_rows, int64_t n_rows, int normalize, float* d_tiled,
+                        int64_t dst_row0, void* stream) {
+  SSKD_REQUIRE(n_rows >= 0, "index_add_rows: n_rows < 0");
+  if (n_rows == 0) return SSKD_OK;
+  SSKD_REQUIRE(d_rows && d_tiled, "index_add_rows: null pointer");
+  SSKD_REQUIRE(dst_row0 >= 0 && dst_row0 % TILE_ROWS == 0,
+               "index_add_rows: dst_row0 must be a non-negative multiple of %d", TILE_ROWS);
+  const int64_t tiles = sskd::ceil_div(n_rows, TILE_ROWS);
+  hipLaunchKernelGGL(index_add_rows_kernel, dim3((unsigned)tiles), dim3(256), 0,
+                     sskd::as_stream(stream), reinterpret_cast<const float4*>(d_rows), n_rows,
+                     normalize, reinterpret_cast<float4*>(d_tiled), dst_row0 / TILE_ROWS);
+  return sskd::check_launch("index_add_rows_kernel");
+}
+
+int sskd_index_get_rows(const float* d_tiled, int64_t row0, int64_t n_rows, float* d_rows,
+                        void* stream) {
+  SSKD_REQUIRE(n_rows >= 0 && row0 >= 0, "index_get_rows: negative range");
+  if (n_rows == 0) return SSKD_OK;
+  SSKD_REQUIRE(d_rows && d_tiled, "index_get_rows: null pointer");
+  const int64_t total = n_rows * CHUNKS;
+  int64_t blocks = sskd::ceil_div(total, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(index_get_rows_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     sskd::as_stream(stream), reinterpret_cast<const float4*>(d_tiled), row0,
+                     n_rows, reinterpret_cast<float4*>(d_rows));
+  return sskd::check_launch("index_get_rows_kernel");
+}
+
+int sskd_l2_normalize_rows(float* d_x, int64_t n_rows, int dim, void* stream) {
+  SSKD_REQUIRE(n_rows >= 0 && dim > 0, "l2_normalize_rows: bad shape");
+  if (n_rows == 0) return SSKD_OK;
+  SSKD_REQUIRE(d_x, "l2_normalize_rows: null pointer");
+  hipLaunchKernelGGL(l2_normalize_rows_kernel, dim3((unsigned)sskd::ceil_div(n_rows, 4)),
+                     dim3(256), 0, sskd::as_stream(stream), d_x, n_rows, dim);
+  return sskd::check_launch("l2_normalize_rows_kernel");
+}
+
+size_t sskd_index_search_workspace_bytes(int64_t n_rows, int nq, int k) {
+  if (n_rows < 0 || nq <= 0 || k <= 0) return 0;
+  const Plan pl = make_plan(n_rows, nq, k);
+  return align256(pl.part_elems * sizeof(float)) + align256(pl.part_elems * sizeof(int)) +
+         align256((size_t)nq * sizeof(float)) + align256((size_t)nq * sizeof(int));
+}
+
+int sskd_index_search_plan(int64_t n_rows, int nq, int k, int* queries_per_block,
+                           int* corpus_passes, int* n_slices, int* waves_per_block,
+                           int* scan_passes) {
+  SSKD_REQUIRE(n_rows >= 0 && nq > 0 && k > 0, "index_search_plan: bad shape");
+  const Plan pl = make_plan(n_rows, nq, k);
+  if (queries_per_block) *queries_per_block = 32 * pl.QB;
+  if (corpus_passes) *corpus_passes = pl.n_qblocks * pl.passes;
+  if (n_slices) *n_slices = pl.n_slices;
+  if (waves_per_block) *waves_per_block = pl.waves;
+  if (scan_passes) *scan_passes = pl.passes;
+  return SSKD_OK;
+}
+
+int sskd_index_search(const float* d_tiled, int64_t n_rows, const float* d_queries, int nq, int k,
+                      int64_t id_offset, float* d_out_scores, int64_t* d_out_ids,
+                      void* d_workspace, size_t workspace_bytes, void* stream) {
+  return sskd_index_search_profiled(d_tiled, n_rows, d_queries, nq, k, id_offset, d_out_scores,
+                                    d_out_ids, d_workspace, workspace_bytes, stream, nullptr,
+                                    nullptr);
+}
+
+int sskd_index_search_profiled(const float* d_tiled, int64_t n_rows, const float* d_queries, int nq,
+                               int k, int64_t id_offset, float* d_out_scores, int64_t* d_out_ids,
+                               void* d_workspace, size_t workspace_bytes, void* stream,
+                               void* ev_scan_begin, void* ev_scan_end) {
+  SSKD_REQUIRE(n_rows >= 0, "index_search: n_rows < 0");
+  SSKD_REQUIRE(nq >= 0, "index_search: nq < 0");
+  SSKD_REQUIRE(k >= 1 && k <= SSKD_K_MAX, "index_search: k=%d outside [1, %d]", k, SSKD_K_MAX);
+  SSKD_REQUIRE(n_rows < ((int64_t)1 << 31) - 64, "index_search: shard too large for int32 row ids");
+  if (nq == 0) return SSKD_OK;
+  SSKD_REQUIRE(d_queries && d_out_scores && d_out_ids, "index_search: null pointer");
+  hipStream_t st = sskd::as_stream(stream);
+  if (n_rows == 0) {
+    const int64_t n = (int64_t)nq * k;
+    hipLaunchKernelGGL(fill_empty_kernel, dim3((unsigned)sskd::ceil_div(n, 256)), dim3(256), 0, st,
+                       d_out_scores, d_out_ids, n);
+    return sskd::check_launch("fill_empty_kernel");
+  }
+  SSKD_REQUIRE(d_tiled, "index_search: null index");
+  const size_t need = sskd_index_search_workspace_bytes(n_rows, nq, k);
+  if (!d_workspace || workspace_bytes < need)
+    return sskd::fail(SSKD_ERR_WORKSPACE, "index_search: workspace %zu B < required %zu B",
+                      workspace_bytes, need);
+  const Plan pl = make_plan(n_rows, nq, k);
+  char* ws = static_cast<char*>(d_workspace);
+  float* part_scores = reinterpret_cast<float*>(ws);
+  ws += align256(pl.part_elems * sizeof(float));
+  int* part_ids = reinterpret_cast<int*>(ws);
+  ws += align256(pl.part_elems * sizeof(int));
+  float* ub_scores = reinterpret_cast<float*>(ws);
+  ws += align256((size_t)nq * sizeof(float));
+  int* ub_ids = reinterpret_cast<int*>(ws);
+
+  ScanParams sp{};
+  sp.tiled = d_tiled;
+  sp.queries = d_queries;
+  sp.part_scores = part_scores;
+  sp.part_ids = part_ids;
+  sp.ub_scores = ub_scores;
+  sp.ub_ids = ub_ids;
+  sp.n_rows = n_rows;
+  sp.n_tiles = pl.n_tiles;
+  sp.nq = nq;
+  sp.n_slices = pl.n_slices;
+  sp.tiles_per_slice = pl.tiles_per_slice;
+  sp.lists_per_query = pl.lists_per_query;
+
+  for (int pass = 0; pass < pl.passes; ++pass) {
+    if (pass == 0 && ev_scan_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_scan_begin), st);
+    int rc = pass == 0 ? dispatch_scan<false>(pl, sp, st) : dispatch_scan<true>(pl, sp, st);
+    if (pass == 0 && ev_scan_end) (void)hipEventRecord(static_cast<hipEvent_t>(ev_scan_end), st);
+    if (rc != SSKD_OK) return rc;
+    MergeParams<int> mp{};
+    mp.scores = part_scores;
+    mp.ids = part_ids;
+    mp.list_stride = pl.K;
+    mp.q_stride = (int64_t)pl.lists_per_query * pl.K;
+    mp.k_in = pl.K;
+    mp.n_cand = pl.lists_per_query * pl.K;
+    mp.nq = nq;
+    mp.out_scores = d_out_scores;
+    mp.out_ids = d_out_ids;
+    mp.out_stride = k;
+    mp.out_off = pass * SSKD_K_PASS;
+    mp.count = (k - pass * SSKD_K_PASS) < SSKD_K_PASS ? (k - pass * SSKD_K_PASS) : SSKD_K_PASS;
+    mp.id_offset = id_offset;
+    mp.ub_scores = (pass + 1 < pl.passes) ? ub_scores : nullptr;
+    mp.ub_ids = ub_ids;
+    hipLaunchKernelGGL(merge_topk_kernel<int>, dim3((unsigned)sskd::ceil_div(nq, 4)), dim3(256), 0,
+                       st, mp);
+    rc = sskd::check_launch("merge_topk_kernel");
+    if (rc != SSKD_OK) return rc;
+  }
+  return SSKD_OK;
+}
+
+int sskd_topk_merge(const float* d_scores, const int64_t* d_ids, int n_lists, int nq, int k_in,
+                    int k_out, float* d_out_scores, int64_t* d_out_ids, void* stream) {
+  SSKD_REQUIRE(n_lists >= 1 && nq >= 0 && k_in >= 1 && k_out >= 1, "topk_merge: bad shape");
+  if (nq == 0) return SSKD_OK;
+  SSKD_REQUIRE(d_scores && d_ids && d_out_scores && d_out_ids, "topk_merge: null pointer");
+  MergeParams<int64_t> mp{};
+  mp.scores = d_scores;
+  mp.ids = d_ids;
+  mp.list_stride = (int64_t)nq * k_in;
+  mp.q_stride = k_in;
+  mp.k_in = k_in;
+  mp.n_cand = n_lists * k_in;
+  mp.nq = nq;
+  mp.out_scores = d_out_scores;
+  mp.out_ids = d_out_ids;
+  mp.out_stride = k_out;
+  mp.out_off = 0;
+  mp.count = k_out;
+  mp.id_offset = 0;
+  mp.ub_scores = nullptr;
+  mp.ub_ids = nullptr;
+  hipLaunchKernelGGL(merge_topk_kernel<int64_t>, dim3((unsigned)sskd::ceil_div(nq, 4)), dim3(256),
+                     0, sskd::as_stream(stream), mp);
+  return sskd::check_launch("merge_topk_kernel<int64>");
+}
+
+int sskd_similarity(const float* d_q, int nq, const float* d_d, int nd, int dim, float* d_out,
+                    void* stream) {
+  SSKD_REQUIRE(nq >= 0 && nd >= 0 && dim > 0, "similarity: bad shape");
+  SSKD_REQUIRE(dim % 8 == 0, "similarity: dim must be a multiple of 8");
+  if (nq == 0 || nd == 0) return SSKD_OK;
+  SSKD_REQUIRE(d_q && d_d && d_out, "similarity: null pointer");
+  hipLaunchKernelGGL(similarity_kernel,
+                     dim3((unsigned)sskd::ceil_div(nd, 32), (unsigned)sskd::ceil_div(nq, 32)),
+                     dim3(64), 0, sskd::as_stream(stream), d_q, nq, d_d, nd, dim, d_out);
+  return sskd::check_launch("similarity_kernel");
+}
+
+}  // extern "C"

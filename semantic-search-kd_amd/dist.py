@@ -1,0 +1,80 @@
+"""Row-sharded search across the GPUs of one node (one process per GPU, RCCL over xGMI).
+
+The reference has a single in-process index (src/serve/app.py:49-66); BASELINE.json's
+north star shards the corpus row-wise, so this is the one place the path has a real
+exchange step:
+
+    every rank: scan its shard  ->  (scores fp32, global ids int64)[nq, k]
+    all ranks : all-gather      ->  [G, nq, k]                (1.2 MB / rank at nq=10k, k=10)
+    every rank: merge G*k -> k per query (``sskd_topk_merge``; ties: lower global id)
+
+The collective goes through ``torch.distributed`` (backend ``nccl`` = RCCL on ROCm) on
+the same stream as the kernels.  ``local_search`` / ``merge`` are injectable so that the
+sharding logic can be exercised with ``gloo`` on CPU in the tests.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+
+from . import _native
+
+
+def shard_bounds(n_rows: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous row range ``[lo, hi)`` of ``rank``: ceil(N / G) rows per rank."""
+    per = -(-n_rows // world_size)
+    lo = min(rank * per, n_rows)
+    return lo, min(lo + per, n_rows)
+
+
+def hip_merge(scores: torch.Tensor, ids: torch.Tensor, k_out: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``[G, nq, k_in]`` device lists -> ``[nq, k_out]`` via the HIP merge kernel."""
+    lib = _native.load()
+    g, nq, k_in = scores.shape
+    out_s = torch.empty((nq, k_out), dtype=torch.float32, device=scores.device)
+    out_i = torch.empty((nq, k_out), dtype=torch.int64, device=scores.device)
+    _native.check(
+        lib.sskd_topk_merge(
+            scores.contiguous().data_ptr(),
+            ids.contiguous().data_ptr(),
+            g,
+            nq,
+            k_in,
+            k_out,
+            out_s.data_ptr(),
+            out_i.data_ptr(),
+            int(torch.cuda.current_stream(scores.device).cuda_stream),
+        )
+    )
+    return out_s, out_i
+
+
+class ShardedSearcher:
+    """Search a corpus whose rows are split over the ranks of a process group."""
+
+    def __init__(
+        self,
+        local_search: Callable[[torch.Tensor, int], Tuple[torch.Tensor, torch.Tensor]],
+        group=None,
+        merge: Optional[Callable[[torch.Tensor, torch.Tensor, int], Tuple[torch.Tensor, torch.Tensor]]] = None,
+    ) -> None:
+        """``local_search(queries, k)`` must return this rank's ``(scores, GLOBAL ids)``
+        (e.g. ``FAISSIndexBuilder(id_offset=lo).search_device``)."""
+        self.local_search = local_search
+        self.group = group
+        self.merge = merge or hip_merge
+
+    def search(self, queries: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        import torch.distributed as dist
+
+        s, i = self.local_search(queries, k)
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return s, i
+        world = dist.get_world_size(self.group)
+        nq = s.shape[0]
+        all_s = torch.empty((world, nq, k), dtype=s.dtype, device=s.device)
+        all_i = torch.empty((world, nq, k), dtype=i.dtype, device=i.device)
+        dist.all_gather_into_tensor(all_s, s.contiguous(), group=self.group)
+        dist.all_gather_into_tensor(all_i, i.contiguous(), group=self.group)
+        return self.merge(all_s, all_i, k)

@@ -1,0 +1,64 @@
+"""The C-ABI library loads and exports every symbol that include/sskd_amd.h declares (no GPU)."""
+import re
+
+from conftest import REPO
+
+
+def _declared_symbols():
+    text = (REPO / "include" / "sskd_amd.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sskd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_symbols():
+    syms = _declared_symbols()
+    assert "sskd_index_search" in syms and "sskd_encoder_forward" in syms and len(syms) >= 15
+
+
+def test_library_exports_every_declared_symbol(native_lib):
+    from semantic_search_kd_amd import _native
+
+    declared = _declared_symbols()
+    for name in declared:
+        assert hasattr(native_lib, name), f"libsskd_amd.so does not export {name}"
+    # and the ctypes table binds exactly the declared set
+    assert sorted(_native.SIGNATURES) == declared
+
+
+def test_abi_version_and_pure_host_queries(native_lib):
+    assert native_lib.sskd_abi_version() == 1
+    assert native_lib.sskd_index_padded_rows(0) == 0
+    assert native_lib.sskd_index_padded_rows(1) == 32
+    assert native_lib.sskd_index_padded_rows(1_000_000) == 1_000_000
+    assert native_lib.sskd_index_padded_rows(8_841_823) == 8_841_824
+    assert native_lib.sskd_index_tiled_bytes(1_000_000) == 1_000_000 * 384 * 4
+    assert native_lib.sskd_index_search_workspace_bytes(1_000_000, 10_000, 10) > 0
+
+
+def test_search_plan_reports_geometry(native_lib):
+    import ctypes as C
+
+    qpb, passes, slices, waves, scans = (C.c_int() for _ in range(5))
+    rc = native_lib.sskd_index_search_plan(1_000_000, 10_000, 10, qpb, passes, slices, waves, scans)
+    assert rc == 0
+    assert qpb.value in (32, 64) and waves.value == 8 and scans.value == 1
+    assert passes.value == -(-10_000 // qpb.value)
+    assert slices.value % 8 == 0
+    rc = native_lib.sskd_index_search_plan(1000, 1, 100, qpb, passes, slices, waves, scans)
+    assert rc == 0 and scans.value == 4 and qpb.value == 32
+
+
+def test_invalid_arguments_are_reported_not_thrown(native_lib):
+    rc = native_lib.sskd_index_search(None, 10, None, 1, 0, 0, None, None, None, 0, None)
+    assert rc == 1
+    assert b"k=0" in native_lib.sskd_last_error()
+    rc = native_lib.sskd_index_add_rows(None, 5, 0, None, 7, None)
+    assert rc == 1
+
+
+def test_product_refuses_cpu_device():
+    import pytest
+    from semantic_search_kd_amd import FAISSIndexBuilder
+
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        FAISSIndexBuilder(embedding_dim=384, device="cpu")
