@@ -9,6 +9,22 @@ as ``semantic_search_kd_amd`` (the sibling alias package points here).
 from . import _native  # noqa: F401
 from .index import FAISSIndexBuilder, IndexHandle, read_flat_ip, write_flat_ip  # noqa: F401
 
+from .weights import BertConfig, synthetic_state_dict  # noqa: F401
+from .encoder import Mi355xSentenceEncoder, build_wordpiece_tokenizer  # noqa: F401
+from .student import StudentModel  # noqa: F401
+from .bench_support import bench_encode, encoder_smoke_embeddings  # noqa: F401
+
 Mi355xIndexBuilder = FAISSIndexBuilder
 
-__all__ = ["FAISSIndexBuilder", "Mi355xIndexBuilder", "IndexHandle", "read_flat_ip", "write_flat_ip"]
+__all__ = [
+    "StudentModel",
+    "Mi355xSentenceEncoder",
+    "FAISSIndexBuilder",
+    "Mi355xIndexBuilder",
+    "IndexHandle",
+    "BertConfig",
+    "synthetic_state_dict",
+    "build_wordpiece_tokenizer",
+    "read_flat_ip",
+    "write_flat_ip",
+]

@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures in this directory (run in the build container, CPU only).
+
+The reference keeps no golden vectors for the hot path, and its own hot-path
+source files / engines are absent here, so fixtures come from:
+
+* search  — inputs built exactly like the reference's only index fixture (tests/conftest.py:65-73:
+            ``np.random.seed(42); randn(10, 384)`` L2-normalised rows in an ``IndexFlatIP``) and the
+            BASELINE cfg-1 shape (1 000 x 100, k = 10); expected outputs from the reference's exact
+            search idiom (``np.matmul`` + ``argsort``: src/kd/eval.py:86, scripts/simple_eval.py:25,35)
+            as restated in oracle/search.py, in BLAS order and in the kernel's fma order.
+* encoder — ``transformers.BertModel`` (the module sentence-transformers executes for the reference's
+            StudentModel) built from an in-memory ``BertConfig`` — nothing is downloaded — loaded
+            with the deterministic synthetic weights of semantic-search-kd_amd/weights.py.  The
+            oracle restatement (oracle/encoder.py) is asserted equal to it here, and the
+            embeddings are stored.  Weights are NOT stored: tests regenerate them from the recipe.
+
+Usage:  python tests/golden/make_golden.py
+"""
+from __future__ import annotations
+
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parent.parent
+sys.path.insert(0, str(REPO))
+
+from oracle import encoder as enc_oracle  # noqa: E402
+from oracle import search as oracle  # noqa: E402
+from semantic_search_kd_amd.weights import BertConfig, synthetic_state_dict  # noqa: E402
+
+
+def make_search_small():
+    np.random.seed(42)  # tests/conftest.py:69-72
+    emb = np.random.randn(10, 384).astype(np.float32)
+    emb = emb / np.linalg.norm(emb, axis=1, keepdims=True)
+    q = oracle.seeded_unit_rows(5, 384, 99)
+    q[0] = emb[3]
+    out = {"corpus": emb, "queries": q}
+    for k in (1, 3, 10, 20):
+        bs, bi = oracle.topk_blas(q, emb, k)
+        fs, fi = oracle.topk_fma(q, emb, k)
+        assert np.array_equal(bi, fi) and np.abs(bs - fs)[bi >= 0].max() < 1e-6
+        out[f"blas_scores_k{k}"], out[f"ids_k{k}"], out[f"fma_scores_k{k}"] = bs, bi, fs
+    np.savez_compressed(HERE / "search_small.npz", **out)
+
+
+def make_search_1k():
+    c = oracle.seeded_unit_rows(1000, 384, 1234)
+    q = oracle.seeded_unit_rows(100, 384, 4321)
+    bs, bi = oracle.topk_blas(q, c, 10)
+    fs, fi = oracle.topk_fma(q, c, 10)
+    assert np.array_equal(bi, fi)
+    # inputs are regenerated from the seeds by the tests; only expected outputs are stored
+    np.savez_compressed(HERE / "search_1k.npz", blas_scores=bs, ids=bi, fma_scores=fs,
+                        corpus_checksum=np.float64(c.astype(np.float64).sum()),
+                        queries_checksum=np.float64(q.astype(np.float64).sum()))
+
+
+def make_pool_norm():
+    g = np.random.Generator(np.random.PCG64(7))
+    h = g.standard_normal((8, 64, 384), dtype=np.float32)
+    lens = [64, 50, 33, 20, 12, 7, 1, 64]
+    mask = np.zeros((8, 64), np.int32)
+    for b, n in enumerate(lens):
+        mask[b, :n] = 1
+    e = enc_oracle.mean_pool_normalize(h, mask, True)
+    e_raw = enc_oracle.mean_pool_normalize(h, mask, False)
+    # torch restatement of sentence_transformers.models.Pooling(mean) + Normalize
+    ht, mt = torch.from_numpy(h), torch.from_numpy(mask).float().unsqueeze(-1)
+    ref = (ht * mt).sum(1) / torch.clamp(mt.sum(1), min=1e-9)
+    assert np.abs(ref.numpy() - e_raw).max() < 1e-6
+    assert np.abs(torch.nn.functional.normalize(ref, p=2, dim=1).numpy() - e).max() < 1e-6
+    assert np.abs(oracle.pool_normalize(h, mask, True) - e).max() < 1e-6
+    np.savez_compressed(HERE / "pool_norm.npz", seed=7, lengths=np.array(lens), pooled=e_raw, normalized=e)
+
+
+def hf_bert(cfg: BertConfig, sd):
+    from transformers import BertConfig as HFConfig
+    from transformers import BertModel
+
+    hf_cfg = HFConfig(
+        vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+        num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+        max_position_embeddings=cfg.max_position_embeddings, type_vocab_size=cfg.type_vocab_size,
+        layer_norm_eps=cfg.layer_norm_eps, hidden_act="gelu", hidden_dropout_prob=0.0,
+        attention_probs_dropout_prob=0.0,
+    )
+    model = BertModel(hf_cfg, add_pooling_layer=False).eval()
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not unexpected, unexpected
+    assert all("position_ids" in m or "pooler" in m for m in missing), missing
+    return model
+
+
+def make_bert(layers: int, tag: str):
+    cfg = BertConfig(num_hidden_layers=layers)
+    sd = synthetic_state_dict(cfg)
+    lengths = [48, 31, 17, 5]
+    ids, mask = enc_oracle.synthetic_token_ids(4, 48, seed=11 + layers, lengths=lengths)
+    model = hf_bert(cfg, sd)
+    with torch.no_grad():
+        out = model(
+            input_ids=torch.from_numpy(ids).long(), attention_mask=torch.from_numpy(mask).long(),
+            output_hidden_states=True,
+        )
+    hf_hidden = [h.numpy() for h in out.hidden_states]
+    ours = enc_oracle.bert_hidden_states(sd, ids, mask, layers, return_all=True)
+    m = mask.astype(bool)
+    worst = max(float(np.abs(a[m] - b[m]).max()) for a, b in zip(hf_hidden, ours))
+    print(f"[{tag}] oracle vs transformers.BertModel: max |diff| over real tokens = {worst:.3e}")
+    assert worst < 2e-4, worst
+    e_hf = enc_oracle.mean_pool_normalize(hf_hidden[-1], mask, True)
+    e_or = enc_oracle.encode_token_ids(sd, ids, mask, layers)
+    assert np.abs(e_hf - e_or).max() < 1e-5
+    np.savez_compressed(
+        HERE / f"bert_{tag}.npz",
+        layers=layers, input_ids=ids, attention_mask=mask, embeddings=e_hf,
+        layer_mean_abs=np.array([np.abs(h[m]).mean() for h in hf_hidden], np.float64),
+        last_hidden_cls=hf_hidden[-1][:, 0, :].astype(np.float32),
+        oracle_vs_hf_max_abs=np.float64(worst),
+    )
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    make_search_small()
+    make_search_1k()
+    make_pool_norm()
+    make_bert(2, "l2")
+    make_bert(12, "l12")
+    for p in sorted(HERE.glob("*.npz")):
+        print(f"{p.name}: {p.stat().st_size / 1024:.1f} KiB")

@@ -1,0 +1,192 @@
+"""GPU parity of the bf16 encoder path against the fp32 oracle and the committed golden vectors.
+
+Tolerances (floating point, stated here as the north star requires): the HIP path computes in
+bf16 (8-bit mantissa) with fp32 accumulation, the reference in fp32.  For L2-normalised 384-d
+embeddings we require cosine(e_hip, e_ref) >= 0.999 and max |e_hip - e_ref| <= 4e-3;
+fp32 kernels (pool + normalise) must agree to 2e-6.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import encoder as enc_oracle
+from oracle import search as oracle
+from semantic_search_kd_amd import BertConfig, Mi355xSentenceEncoder, StudentModel, _native, synthetic_state_dict
+from semantic_search_kd_amd.weights import bf16_round, save_model_dir
+
+pytestmark = pytest.mark.gpu
+
+COS_MIN = 0.999
+EMB_ATOL = 4e-3
+
+
+def _stream():
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+def _cos(a, b):
+    return (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+
+
+@pytest.fixture(scope="module")
+def enc_l2(gpu):
+    cfg = BertConfig(num_hidden_layers=2)
+    return Mi355xSentenceEncoder.from_synthetic(cfg, device="cuda:0"), cfg, synthetic_state_dict(cfg)
+
+
+def test_pool_normalize_matches_golden(gpu, native_lib):
+    gold = np.load(GOLDEN / "pool_norm.npz")
+    g = np.random.Generator(np.random.PCG64(int(gold["seed"])))
+    h = g.standard_normal((8, 64, 384), dtype=np.float32)
+    mask = np.zeros((8, 64), np.int32)
+    for b, n in enumerate(gold["lengths"]):
+        mask[b, :n] = 1
+    dh, dm = torch.from_numpy(h).cuda(), torch.from_numpy(mask).cuda()
+    out = torch.empty((8, 384), device="cuda")
+    for normalize, key in ((1, "normalized"), (0, "pooled")):
+        _native.check(native_lib.sskd_pool_normalize(dh.data_ptr(), 0, dm.data_ptr(), 8, 64, normalize, out.data_ptr(), _stream()))
+        np.testing.assert_allclose(out.cpu().numpy(), gold[key], rtol=0, atol=2e-6)
+    # bf16 hidden input: same result on the bf16-rounded values
+    hb = torch.from_numpy(h).cuda().to(torch.bfloat16)
+    _native.check(native_lib.sskd_pool_normalize(hb.data_ptr(), 1, dm.data_ptr(), 8, 64, 1, out.data_ptr(), _stream()))
+    want = oracle.pool_normalize(hb.float().cpu().numpy(), mask, True)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0, atol=2e-6)
+    # all-masked row: mean of nothing is 0 (clamp 1e-9), normalise leaves 0 (clamp 1e-12)
+    dm0 = torch.zeros((8, 64), dtype=torch.int32, device="cuda")
+    _native.check(native_lib.sskd_pool_normalize(dh.data_ptr(), 0, dm0.data_ptr(), 8, 64, 1, out.data_ptr(), _stream()))
+    assert not out.cpu().numpy().any()
+
+
+@pytest.mark.parametrize("tag", ["l2", "l12"])
+def test_encoder_matches_transformers_golden(gpu, tag):
+    """Embeddings vs the committed output of transformers.BertModel (fp32) on synthetic weights."""
+    gold = np.load(GOLDEN / f"bert_{tag}.npz")
+    cfg = BertConfig(num_hidden_layers=int(gold["layers"]))
+    enc = Mi355xSentenceEncoder.from_synthetic(cfg, device="cuda:0")
+    emb = enc.encode_token_ids(gold["input_ids"], gold["attention_mask"]).cpu().numpy()
+    assert emb.shape == (4, 384) and emb.dtype == np.float32
+    np.testing.assert_allclose(np.linalg.norm(emb, axis=1), 1.0, atol=1e-5)  # test_model_validation.py:80-89
+    cos = _cos(emb, gold["embeddings"])
+    assert cos.min() >= COS_MIN, cos
+    assert np.abs(emb - gold["embeddings"]).max() <= EMB_ATOL
+    # CLS hidden state of the last layer (bf16 output vs fp32 golden)
+    hs = enc.hidden_states(gold["input_ids"], gold["attention_mask"]).float().cpu().numpy()
+    cls = hs[:, 0, :]
+    assert _cos(cls, gold["last_hidden_cls"]).min() >= COS_MIN
+
+
+def test_hidden_states_vs_oracle_same_weights(enc_l2):
+    """Per-token hidden states vs the fp32 oracle run on the SAME bf16-rounded weights: isolates
+    kernel arithmetic (bf16 activations) from weight quantisation."""
+    enc, cfg, sd = enc_l2
+    sd_b = {k: (bf16_round(v) if v.ndim == 2 else v) for k, v in sd.items()}
+    ids, mask = enc_oracle.synthetic_token_ids(6, 80, seed=5, lengths=[80, 64, 33, 32, 31, 2])
+    got = enc.hidden_states(ids, mask).float().cpu().numpy()
+    want = enc_oracle.bert_hidden_states(sd_b, ids, mask, cfg.num_hidden_layers)
+    m = mask.astype(bool)
+    # LayerNorm output is O(1) per element; bf16 resolution there is 2^-8
+    assert np.abs(got[m] - want[m]).max() < 6e-2
+    assert np.abs(got[m] - want[m]).mean() < 6e-3
+    assert _cos(got[m], want[m]).min() > 0.9995
+
+
+@pytest.mark.parametrize("B,S,lengths", [
+    (1, 1, None),            # [CLS]-only would be length 2; S=1 exercises the degenerate tile
+    (1, 7, None),
+    (3, 32, [32, 17, 2]),
+    (2, 33, [33, 9]),
+    (5, 100, [100, 77, 64, 3, 50]),
+    (2, 256, [256, 130]),    # BASELINE cfg 2 sequence length
+    (2, 300, [300, 257]),    # more than one 256-query block
+    (1, 512, None),          # maximum length (config.py:29)
+])
+def test_encoder_shapes_and_ragged_masks(enc_l2, B, S, lengths):
+    enc, cfg, sd = enc_l2
+    ids, mask = enc_oracle.synthetic_token_ids(B, S, seed=100 + S, lengths=lengths)
+    emb = enc.encode_token_ids(ids, mask).cpu().numpy()
+    want = enc_oracle.encode_token_ids(sd, ids, mask, cfg.num_hidden_layers)
+    assert _cos(emb, want).min() >= COS_MIN
+    assert np.abs(emb - want).max() <= EMB_ATOL
+
+
+def test_padding_invariance(enc_l2):
+    """An embedding must not depend on batch-mates or on how far the row is padded."""
+    enc, cfg, sd = enc_l2
+    ids, mask = enc_oracle.synthetic_token_ids(4, 96, seed=9, lengths=[96, 40, 23, 64])
+    full = enc.encode_token_ids(ids, mask).cpu().numpy()
+    alone = enc.encode_token_ids(ids[1:2, :40], mask[1:2, :40]).cpu().numpy()
+    np.testing.assert_allclose(alone[0], full[1], atol=1e-5)
+    # pad token ids behind the mask are irrelevant
+    ids2 = ids.copy()
+    ids2[1, 40:] = 777
+    again = enc.encode_token_ids(ids2, mask).cpu().numpy()
+    assert np.array_equal(again[1], full[1])
+    # determinism (test_model_validation.py:100-110 asks 1e-5; the kernels are bit-deterministic)
+    assert np.array_equal(enc.encode_token_ids(ids, mask).cpu().numpy(), full)
+
+
+def test_unnormalized_and_out_of_range_ids(enc_l2):
+    enc, cfg, sd = enc_l2
+    ids, mask = enc_oracle.synthetic_token_ids(2, 20, seed=3)
+    raw = enc.encode_token_ids(ids, mask, normalize=False).cpu().numpy()
+    want = enc_oracle.encode_token_ids(sd, ids, mask, cfg.num_hidden_layers, normalize=False)
+    assert _cos(raw, want).min() >= COS_MIN
+    np.testing.assert_allclose(np.linalg.norm(raw, axis=1), np.linalg.norm(want, axis=1), rtol=2e-2)
+    with pytest.raises(_native.NativeError, match="exceeds max"):
+        enc.encode_token_ids(np.zeros((1, 513), np.int32))
+
+
+def _vocab():
+    words = ["[PAD]"] + [f"[unused{i}]" for i in range(99)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"]
+    words += ["query", "passage", ":", "what", "is", "machine", "learning", "how", "does", "search", "work",
+              "semantic", "the", "a", "of", "deep", "neural", "network", "##s", "##ing", "vector", "index",
+              "hello", "world", "test", "document", "text", "##1", "##2", "##3", ".", "?", "!", "e", "##5"]
+    return words
+
+
+def test_text_path_and_student_model(gpu, tmp_path):
+    """End to end: local model directory (config.json + model.safetensors + vocab.txt) ->
+    StudentModel -> encode / encode_queries / encode_documents, compared with the oracle run on the
+    very ids the tokenizer produced (text -> ids parity is unpinned offline: no e5 vocab on disk)."""
+    vocab = _vocab()
+    cfg = BertConfig(vocab_size=len(vocab), num_hidden_layers=2)
+    sd = synthetic_state_dict(cfg)
+    mdir = tmp_path / "e5-small-v2-synthetic"
+    save_model_dir(mdir, cfg, sd)
+    (mdir / "vocab.txt").write_text("\n".join(vocab))
+    student = StudentModel(str(mdir), device="cuda:0")
+    assert student.embedding_dim == 384 and student.device == "cuda:0" and student.is_e5
+    texts = ["What is machine learning?", "hello world", "Semantic search networks!", ""]
+    emb = student.encode(texts, batch_size=2)
+    assert emb.shape == (4, 384) and emb.dtype == np.float32
+    np.testing.assert_allclose(np.linalg.norm(emb, axis=1), 1.0, atol=1e-5)
+    tok = student.model.tokenize(texts)
+    assert tok["input_ids"][1, 0] == 101 and tok["input_ids"][3].tolist()[:2] == [101, 102]  # empty text -> [CLS][SEP]
+    want = enc_oracle.encode_token_ids(sd, tok["input_ids"], tok["attention_mask"], 2)
+    assert _cos(emb, want).min() >= COS_MIN
+    # single string in -> [1, 384] out through StudentModel.encode (wrapped into a list)
+    one = student.encode("hello world")
+    assert one.shape == (1, 384)
+    np.testing.assert_allclose(one[0], emb[1], atol=1e-5)  # batch-size / order independence
+    # E5 prefixes (tests/test_student_model.py:72-102)
+    q = student.encode_queries("hello world")
+    q_manual = student.encode(["query: hello world"])
+    d = student.encode_documents(["hello world"], batch_size=4)
+    d_manual = student.encode(["passage: hello world"])
+    assert np.array_equal(q, q_manual) and np.array_equal(d, d_manual)
+    assert not np.allclose(q, one)
+    sims = student.compute_similarity(q, np.concatenate([d, emb]))
+    assert sims.shape == (1, 5) and np.all(sims <= 1.0001) and np.all(sims >= -1.0001)
+    np.testing.assert_allclose(sims, q @ np.concatenate([d, emb]).T, atol=1e-6)
+    # long text is truncated to max_length and keeps [SEP]
+    long = student.model.tokenize(["test " * 2000])
+    assert long["input_ids"].shape[1] == student.max_length and long["input_ids"][0, -1] == 102
+    student.cleanup()
+
+
+def test_model_name_is_never_fetched(gpu):
+    with pytest.raises(FileNotFoundError, match="never downloads"):
+        StudentModel("intfloat/e5-small-v2", device="cuda:0")
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        StudentModel("whatever", device="cpu")
