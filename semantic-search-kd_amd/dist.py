@@ -73,8 +73,9 @@ class ShardedSearcher:
             return s, i
         world = dist.get_world_size(self.group)
         nq = s.shape[0]
-        all_s = torch.empty((world, nq, k), dtype=s.dtype, device=s.device)
-        all_i = torch.empty((world, nq, k), dtype=i.dtype, device=i.device)
+        # concatenation form [G * nq, k] (accepted by RCCL and gloo alike), viewed as [G, nq, k]
+        all_s = torch.empty((world * nq, k), dtype=s.dtype, device=s.device)
+        all_i = torch.empty((world * nq, k), dtype=i.dtype, device=i.device)
         dist.all_gather_into_tensor(all_s, s.contiguous(), group=self.group)
         dist.all_gather_into_tensor(all_i, i.contiguous(), group=self.group)
-        return self.merge(all_s, all_i, k)
+        return self.merge(all_s.view(world, nq, k), all_i.view(world, nq, k), k)

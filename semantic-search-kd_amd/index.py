@@ -317,7 +317,7 @@ class FAISSIndexBuilder:
             self.reserve(vecs.shape[0])
             step = 1 << 18  # stream the (memory-mapped) matrix in 400 MB slabs
             for lo in range(0, vecs.shape[0], step):
-                self.add(np.ascontiguousarray(vecs[lo : lo + step]))
+                self.add(np.array(vecs[lo : lo + step], dtype=np.float32, copy=True))
         finally:
             self.metric = metric
         ids_path = d / "doc_ids.json"

@@ -6,6 +6,8 @@ symbol check); ``-m gpu`` runs on the MI355X box and calls the HIP path through 
 import sys
 from pathlib import Path
 
+import pyarrow  # noqa: F401  (imported first: pandas' lazy import of it failed once on a GPU box after torch)
+import pyarrow.parquet  # noqa: F401
 import pytest
 
 REPO = Path(__file__).resolve().parent.parent

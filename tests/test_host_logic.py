@@ -1,0 +1,174 @@
+"""Host-side logic that needs no GPU: weight recipe, fragment tiling, index file format,
+StudentModel behaviour (encoder mocked, like the reference's tests/test_student_model.py)."""
+import json
+import struct
+from unittest.mock import MagicMock, patch
+
+import numpy as np
+import pytest
+
+from semantic_search_kd_amd import BertConfig, read_flat_ip, synthetic_state_dict, write_flat_ip
+from semantic_search_kd_amd import weights as W
+
+
+# ------------------------------------------------------------------ weights
+def test_synthetic_weights_are_platform_independent():
+    t = W.synthetic_tensor("embeddings.word_embeddings.weight", (4,), 1.0)
+    # splitmix64 known-answer: first output for seed 0 is 0xE220A8397B1DCDAF
+    assert int(W._splitmix64(np.array([0], np.uint64))[0]) == 0xE220A8397B1DCDAF
+    assert t.dtype == np.float32 and np.all(np.abs(t) < 1.0)
+    again = W.synthetic_tensor("embeddings.word_embeddings.weight", (4,), 1.0)
+    other = W.synthetic_tensor("embeddings.position_embeddings.weight", (4,), 1.0)
+    assert np.array_equal(t, again) and not np.array_equal(t, other)
+
+
+def test_state_dict_has_e5_small_parameter_count():
+    """33 212 160 parameters without the (unused) pooler — SURVEY.md App. B."""
+    sd = synthetic_state_dict(BertConfig())
+    assert sum(v.size for v in sd.values()) == 33_212_160
+    assert sd["encoder.layer.11.intermediate.dense.weight"].shape == (1536, 384)
+    assert abs(float(np.std(sd["encoder.layer.0.output.dense.weight"])) - 0.02) < 1e-3
+
+
+def test_weight_fragment_tiling_matches_kernel_contract():
+    w = np.arange(64 * 48, dtype=np.float32).reshape(64, 48)
+    t = W.tile_weight_fragments(w)
+    assert t.shape == (2, 3, 64, 8)
+    for nt, s, lane, j in ((0, 0, 0, 0), (1, 2, 63, 7), (0, 1, 37, 3), (1, 0, 5, 6)):
+        r, h = lane & 31, lane >> 5
+        assert t[nt, s, lane, j] == w[32 * nt + r, 16 * s + 8 * h + j]
+
+
+def test_bf16_rounding_is_nearest_even():
+    x = np.array([1.0, 1.00390625, 1.01171875, -2.5, 3.1415927], np.float32)
+    bits = W.f32_to_bf16_bits(x)
+    assert bits[0] == 0x3F80
+    assert bits[1] == 0x3F80        # 1 + 2^-8 is a tie -> even (1.0)
+    assert bits[2] == 0x3F82        # 1 + 3*2^-8 is a tie -> even mantissa
+    assert np.allclose(W.bf16_round(x), x, rtol=2 ** -8)
+
+
+def test_model_dir_roundtrip(tmp_path):
+    cfg = BertConfig(vocab_size=300, num_hidden_layers=1)
+    sd = synthetic_state_dict(cfg)
+    W.save_model_dir(tmp_path / "m", cfg, sd)
+    assert W.load_config(tmp_path / "m") == cfg
+    back = W.load_state_dict(tmp_path / "m")
+    assert set(back) == set(sd) and all(np.array_equal(back[k], sd[k]) for k in sd)
+    with pytest.raises(FileNotFoundError, match="LOCAL model directory"):
+        W.load_state_dict(tmp_path / "missing")
+
+
+# ------------------------------------------------------------------ index file
+def test_flat_index_file_layout(tmp_path):
+    """index.faiss is written in faiss' IndexFlatIP layout (fourcc IxFI) — tests/conftest.py:184-188."""
+    v = np.random.default_rng(0).standard_normal((7, 384)).astype(np.float32)
+    write_flat_ip(tmp_path / "index.faiss", v)
+    raw = (tmp_path / "index.faiss").read_bytes()
+    assert raw[:4] == b"IxFI"
+    d, n, _, _, trained, metric = struct.unpack("<iqqqBi", raw[4:4 + 33])
+    assert (d, n, trained, metric) == (384, 7, 1, 0)
+    assert struct.unpack("<Q", raw[37:45])[0] == 7 * 384 and len(raw) == 45 + 7 * 384 * 4
+    assert np.array_equal(np.asarray(read_flat_ip(tmp_path / "index.faiss")), v)
+    (tmp_path / "hnsw.faiss").write_bytes(b"IHNf" + b"\0" * 64)
+    with pytest.raises(ValueError, match="HNSW graph files"):
+        read_flat_ip(tmp_path / "hnsw.faiss")
+    write_flat_ip(tmp_path / "empty.faiss", np.zeros((0, 384), np.float32))
+    assert read_flat_ip(tmp_path / "empty.faiss").shape == (0, 384)
+
+
+def test_builder_argument_validation():
+    from semantic_search_kd_amd import FAISSIndexBuilder
+
+    with pytest.raises(ValueError, match="384"):
+        FAISSIndexBuilder(embedding_dim=768)
+    with pytest.raises(ValueError, match="metric"):
+        FAISSIndexBuilder(embedding_dim=384, metric="l2")
+
+
+# ------------------------------------------------------------------ StudentModel
+def _mock_encoder(n=1):
+    m = MagicMock()
+    m.get_sentence_embedding_dimension.return_value = 384
+    m.max_seq_length = 512
+    m.encode.return_value = np.random.randn(n, 384).astype(np.float32)
+    return m
+
+
+@patch("semantic_search_kd_amd.student.SentenceTransformer")
+def test_default_device_falls_back_to_cpu_string(mock_st):
+    """reference tests/test_student_model.py:12-24 (device=None -> "cpu" without a GPU)."""
+    mock_st.return_value = _mock_encoder()
+    with patch("semantic_search_kd_amd.student.torch") as mock_torch:
+        mock_torch.cuda.is_available.return_value = False
+        from semantic_search_kd_amd.student import StudentModel
+
+        model = StudentModel(model_name="test-model", device=None)
+        assert model.device == "cpu"
+        mock_torch.cuda.is_available.return_value = True
+        assert StudentModel(model_name="test-model").device == "cuda"
+    mock_st.assert_called_with("test-model", device="cuda")
+
+
+@patch("semantic_search_kd_amd.student.SentenceTransformer")
+def test_encode_wraps_single_string_and_calls_encode_once(mock_st):
+    """reference tests/test_student_model.py:38-70."""
+    enc = _mock_encoder(1)
+    mock_st.return_value = enc
+    from semantic_search_kd_amd.student import StudentModel
+
+    model = StudentModel(model_name="test-model", device="cpu")
+    assert model.device == "cpu" and model.embedding_dim == 384 and model.max_length == 512
+    model.encode("hello world")
+    enc.encode.assert_called_once()
+    args, kwargs = enc.encode.call_args
+    assert args[0] == ["hello world"]
+    assert kwargs["convert_to_numpy"] is True and kwargs["normalize_embeddings"] is True
+    enc.encode.return_value = np.random.randn(3, 384).astype(np.float32)
+    assert model.encode(["a", "b", "c"], batch_size=2, show_progress=True).shape == (3, 384)
+    assert enc.encode.call_args[1]["batch_size"] == 2 and enc.encode.call_args[1]["show_progress_bar"] is True
+
+
+@patch("semantic_search_kd_amd.student.SentenceTransformer")
+def test_e5_prefixes(mock_st):
+    """reference tests/test_student_model.py:72-102."""
+    enc = _mock_encoder(1)
+    mock_st.return_value = enc
+    from semantic_search_kd_amd.student import StudentModel
+
+    model = StudentModel(model_name="intfloat/e5-small-v2", device="cpu")
+    model.encode_queries("test query")
+    assert enc.encode.call_args[0][0] == ["query: test query"]
+    model.encode_documents("test document")
+    assert enc.encode.call_args[0][0] == ["passage: test document"]
+    model.encode_documents(["a", "b"], batch_size=16, show_progress=True)
+    assert enc.encode.call_args[0][0] == ["passage: a", "passage: b"] and enc.encode.call_args[1]["batch_size"] == 16
+    plain = StudentModel(model_name="./artifacts/models/kd_student_production", device="cpu")
+    plain.encode_queries(["q"])
+    assert enc.encode.call_args[0][0] == ["q"]                      # no "e5" in the name -> no prefix (auto)
+    forced = StudentModel(model_name="./artifacts/models/kd_student_production", device="cpu", prefix_mode="e5")
+    forced.encode_queries(["q"])
+    assert enc.encode.call_args[0][0] == ["query: q"]
+
+
+@patch("semantic_search_kd_amd.student.SentenceTransformer")
+def test_cleanup_is_safe_and_training_entry_is_refused(mock_st):
+    """reference tests/test_student_model.py:126-137, tests/test_hardening.py:432-453."""
+    mock_st.return_value = _mock_encoder()
+    from semantic_search_kd_amd.student import StudentModel
+
+    model = StudentModel(model_name="test-model", device="cpu")
+    model.cleanup()
+    with pytest.raises(NotImplementedError):
+        model.encode_with_gradients(["x"])
+
+
+def test_student_without_gpu_fails_loudly():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from semantic_search_kd_amd import StudentModel
+
+    with pytest.raises(RuntimeError, match="no CPU path|MI355X"):
+        StudentModel("some/dir", device=None)

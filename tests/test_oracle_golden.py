@@ -1,0 +1,100 @@
+"""Oracle vs the committed golden fixtures (CPU only).
+
+The fixtures come from tests/golden/make_golden.py: search outputs from the reference's exact-search
+idiom (src/kd/eval.py:86) on inputs built like the reference's own index fixture
+(tests/conftest.py:65-73), encoder outputs from transformers.BertModel on synthetic weights.
+"""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import encoder as enc_oracle
+from oracle import search as oracle
+
+
+def test_search_small_conftest_recipe():
+    gold = np.load(GOLDEN / "search_small.npz")
+    np.random.seed(42)  # reference tests/conftest.py:69-72
+    emb = np.random.randn(10, 384).astype(np.float32)
+    emb = emb / np.linalg.norm(emb, axis=1, keepdims=True)
+    assert np.array_equal(emb, gold["corpus"])
+    q = gold["queries"]
+    for k in (1, 3, 10, 20):
+        bs, bi = oracle.topk_blas(q, emb, k)
+        fs, fi = oracle.topk_fma(q, emb, k)
+        assert np.array_equal(bi, gold[f"ids_k{k}"]) and np.array_equal(fi, gold[f"ids_k{k}"])
+        assert np.array_equal(fs, gold[f"fma_scores_k{k}"])
+        np.testing.assert_allclose(bs, gold[f"blas_scores_k{k}"], atol=1e-6)
+    assert gold["ids_k20"][0, 0] == 3 and (gold["ids_k20"][:, 10:] == -1).all()
+
+
+def test_search_1k_cfg1_shape():
+    gold = np.load(GOLDEN / "search_1k.npz")
+    c = oracle.seeded_unit_rows(1000, 384, 1234)
+    q = oracle.seeded_unit_rows(100, 384, 4321)
+    assert abs(c.astype(np.float64).sum() - float(gold["corpus_checksum"])) < 1e-6
+    fs, fi = oracle.topk_fma(q, c, 10)
+    assert np.array_equal(fi, gold["ids"]) and np.array_equal(fs, gold["fma_scores"])
+    bs, bi = oracle.topk_blas(q, c, 10)
+    assert np.array_equal(bi, gold["ids"])
+    np.testing.assert_allclose(bs, gold["blas_scores"], atol=1e-6)
+    # third witness: torch.topk(Q @ C.T) (BASELINE.md §3 "exact oracle")
+    import torch
+
+    ts, ti = torch.topk(torch.from_numpy(q) @ torch.from_numpy(c).T, 10, dim=1)
+    assert np.array_equal(ti.numpy(), gold["ids"])
+    np.testing.assert_allclose(ts.numpy(), gold["blas_scores"], atol=1e-6)
+
+
+def test_topk_semantics_ties_padding_nan():
+    s = np.array([[0.5, 0.9, 0.9, np.nan, 0.1, -np.inf]], np.float32)
+    ts, ti = oracle.topk_of_scores(s, 5)
+    assert ti.tolist() == [[1, 2, 0, 4, -1]]              # tie -> lower id; NaN / -inf never selected
+    assert ts[0, -1] == np.finfo(np.float32).min          # faiss heap neutral
+    import ctypes  # same rule in the C restatement
+
+    from oracle import native
+
+    out_s, out_i = np.empty((1, 5), np.float32), np.empty((1, 5), np.int64)
+    native.load().oracle_topk_of_scores(np.ascontiguousarray(s), 1, 6, 5, 0, out_s, out_i)
+    assert out_i.tolist() == ti.tolist() and np.array_equal(out_s, ts)
+    del ctypes
+
+
+def test_merge_of_shards_equals_whole():
+    c = oracle.seeded_unit_rows(700, 384, 3)
+    q = oracle.seeded_unit_rows(9, 384, 4)
+    whole = oracle.topk_fma(q, c, 10)
+    parts = [oracle.topk_fma(q, c[lo:hi], 10, id_offset=lo) for lo, hi in ((0, 5), (5, 350), (350, 700))]
+    ms, mi = oracle.topk_merge(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]), 10)
+    assert np.array_equal(mi, whole[1]) and np.array_equal(ms, whole[0])
+
+
+def test_pool_norm_golden():
+    gold = np.load(GOLDEN / "pool_norm.npz")
+    g = np.random.Generator(np.random.PCG64(int(gold["seed"])))
+    h = g.standard_normal((8, 64, 384), dtype=np.float32)
+    mask = np.zeros((8, 64), np.int32)
+    for b, n in enumerate(gold["lengths"]):
+        mask[b, :n] = 1
+    np.testing.assert_allclose(oracle.pool_normalize(h, mask, True), gold["normalized"], atol=1e-6)
+    np.testing.assert_allclose(oracle.pool_normalize(h, mask, False), gold["pooled"], atol=1e-6)
+    np.testing.assert_allclose(enc_oracle.mean_pool_normalize(h, mask, True), gold["normalized"], atol=1e-7)
+    np.testing.assert_allclose(np.linalg.norm(gold["normalized"], axis=1), 1.0, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["l2", "l12"])
+def test_encoder_oracle_matches_transformers_golden(tag):
+    """oracle/encoder.py reproduces the committed transformers.BertModel outputs."""
+    from semantic_search_kd_amd import BertConfig, synthetic_state_dict
+
+    gold = np.load(GOLDEN / f"bert_{tag}.npz")
+    layers = int(gold["layers"])
+    sd = synthetic_state_dict(BertConfig(num_hidden_layers=layers))
+    hs = enc_oracle.bert_hidden_states(sd, gold["input_ids"], gold["attention_mask"], layers, return_all=True)
+    m = gold["attention_mask"].astype(bool)
+    np.testing.assert_allclose([np.abs(h[m]).mean() for h in hs], gold["layer_mean_abs"], rtol=1e-5)
+    np.testing.assert_allclose(hs[-1][:, 0, :], gold["last_hidden_cls"], atol=5e-5)
+    emb = enc_oracle.mean_pool_normalize(hs[-1], gold["attention_mask"])
+    np.testing.assert_allclose(emb, gold["embeddings"], atol=1e-5)
+    assert float(gold["oracle_vs_hf_max_abs"]) < 2e-4
