@@ -162,7 +162,7 @@ typedef struct sskd_encoder_layer_weights {
   const float* ln1_b;
   const void* w1;     /* bf16 [1536, 384] */
   const float* b1;    /* [1536] */
-  const void* w2;     /* bf16 [384, 1536] */
+  const void* w2;     /* bf16 [384, 1536], tiled chunk-major for the fused MLP (see weights.py) */
   const float* b2;    /* [384] */
   const float* ln2_g;
   const float* ln2_b;

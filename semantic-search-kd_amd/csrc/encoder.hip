@@ -5,21 +5,28 @@
 // (reference: src/serve/app.py:287,385-389; tests/test_model_validation.py:80-89;
 // architecture constants SURVEY.md App. B / configs/kd.yaml:13-19).
 //
-// All GEMMs are computed TRANSPOSED, D^T[feature, token] = W[feature, k] * X^T[k, token]
+// Formulation.  Every GEMM is computed TRANSPOSED, D^T[feature, token] = W[feature, k] * X^T[k, token]
 // with v_mfma_f32_32x32x16_bf16: weights are the A operand (pre-tiled on the host into
-// fragment order, staged through LDS and shared by the workgroup's waves), activations
-// are the B operand (token on the lane, loaded once into registers straight from the
-// row-major [T, 384] activation matrix).  The 32x32 result then has the token on the
-// lane and 16 features in registers, so bias / GELU / residual / LayerNorm / softmax
-// are lane-local and an accumulator tile can feed the next MFMA as its B operand
-// without leaving registers (attention P*V).
+// fragment order, staged through LDS and shared by the workgroup's waves), activations are the
+// B operand with the TOKEN ON THE LANE.  A 32x32 result then has the token on the lane and 16
+// features in registers, so bias / GELU / residual / LayerNorm / softmax are lane-local and an
+// accumulator tile can feed the next MFMA as its B operand (attention P*V).
 //
-// Kernels per layer (hidden H = 384, 12 heads x 32, FFN 1536):
-//   gemm_k384_kernel<QKV>   X -> Q (pre-scaled), K head-major [B,12,S,32], V^T [B,12,32,S]
-//   attention_kernel        softmax(QK^T/sqrt(32) + mask) V  -> ctx [T,384]
-//   gemm_n384_ln_kernel<1>  X1 = LN(X  + ctx Wo^T + bo)
-//   gemm_k384_kernel<GELU>  Hh = gelu(X1 W1^T + b1)           [T,1536]
-//   gemm_n384_ln_kernel<4>  X2 = LN(X1 + Hh W2^T + b2)
+// Activation layout ("fragment order").  A [T, K] activation lives in HBM as
+//     [T/32 token tiles][K/16 k-steps][64 lanes][8 bf16]
+// where lane l of fragment (tt, s) holds X[32 tt + (l & 31)][16 s + 8 (l >> 5) + j], j = 0..7 -
+// exactly one B operand of the MFMA.  Consequences: (1) a wave loads its activations with
+// contiguous 1 KiB reads, (2) the epilogue of a 32-feature tile - lane (r, h) holds features
+// 8g + 4h + e of token r - stores 4 x 8 bytes per lane that land as 512 contiguous bytes per
+// wave-instruction, with no shuffles.  Sequences are padded to a multiple of 32 tokens
+// (S_pad) so that a token tile never straddles two sequences; token buffers are padded to a
+// multiple of 256 rows so that no kernel needs a bounds check.
+//
+// Kernels per layer (hidden 384, 12 heads x 32, FFN 1536):
+//   gemm_k384_kernel<QKV>   X -> Q (pre-scaled by log2(e)/sqrt(32)), K, V per (batch, head)
+//   attention_kernel        softmax(Q K^T / sqrt(32) + mask) V          -> ctx
+//   gemm_n384_ln_kernel<2>  X1 = LN(X  + ctx Wo^T + bo)
+//   fused_mlp_ln_kernel     X2 = LN(X1 + gelu(X1 W1^T + b1) W2^T + b2)   (hidden 1536 stays on chip)
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -44,335 +51,653 @@ __device__ inline f32x16 zero16() {
   return z;
 }
 
+__device__ inline bf16x8 zero_bf8() {
+  bf16x8 z;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) z[i] = (__bf16)0.f;
+  return z;
+}
+
 __device__ inline float bf2f(__bf16 v) { return (float)v; }
 
-// exact-erf GELU (HF "gelu") with erf by Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7
+// erf-GELU (HF "gelu") = 0.5 x (1 + erf(x / sqrt 2)), erf by Abramowitz-Stegun 7.1.25
+// (|err| <= 2.5e-5, 80x below the bf16 half-ulp of the value produced):
+//   erf(z) = 1 - (a1 t + a2 t^2 + a3 t^3) exp(-z^2),  t = 1 / (1 + p z),  z = |x| / sqrt 2
+// written around u = |x| sqrt(log2(e) / 2) so that exp(-z^2) = exp2(-u^2) needs no extra
+// multiply: 10 VALU + 2 transcendental instructions, no compare / select.
 __device__ inline float gelu_erf(float x) {
-  const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
+  constexpr float KU = 0.84932180028801904f;             // sqrt(log2(e) / 2)
+  constexpr float PU = 0.47047f * 0.70710678118654752f / KU;  // p z = PU u
+  const float u = fabsf(x) * KU;
+  const float t = __builtin_amdgcn_rcpf(fmaf(PU, u, 1.0f));
+  float p = fmaf(0.7478556f, t, -0.0958798f);
+  p = fmaf(p, t, 0.3480242f);
   p *= t;
-  const float e = __builtin_amdgcn_exp2f(-z * z * LOG2E);
-  const float erf_abs = 1.0f - p * e;
-  const float erf = x < 0.f ? -erf_abs : erf_abs;
-  return 0.5f * x * (1.0f + erf);
+  const float e = __builtin_amdgcn_exp2f(-(u * u));
+  const float erf_abs = fmaf(-p, e, 1.0f);
+  const float hx = 0.5f * x;
+  return fmaf(fabsf(hx), erf_abs, hx);
+}
+
+// first vector (lane 0) of fragment (token tile tt, k-step s) of an activation with KS k-steps
+__device__ inline int64_t frag_base(int64_t tt, int s, int KS) { return (tt * KS + s) * 64; }
+
+// Store the 16 accumulator values of a finished 32-feature tile in fragment order: lane (r, h)
+// holds features 8g + 4h + e (g, e = 0..3) of token r, i.e. elements 4h..4h+3 of lane
+// r + 32 (g & 1) of k-step 2 nt + (g >> 1).  `dst` points at fragment (tt, 2 nt) lane 0.
+__device__ inline void store_tile_frag(__bf16* __restrict__ dst, const f32x4 (&v)[4], int r, int h) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    __bf16* p = dst + ((int64_t)((g >> 1) * 64 + r + 32 * (g & 1))) * 8 + 4 * h;
+    *reinterpret_cast<bf16x4*>(p) = __builtin_convertvector(v[g], bf16x4);
+  }
 }
 
 // ------------------------------------------------------------------------- //
-// embeddings + LayerNorm: one wave per token, lanes 0..47 own 8 columns each
+// embeddings + LayerNorm -> fragment-order X [T_pad, 384]
+// one workgroup per 32-token tile; each wave normalises 8 tokens (lanes 0..47 own 8 columns)
+// into an LDS image of the tile, which is then copied out linearly.
 // ------------------------------------------------------------------------- //
 __global__ __launch_bounds__(256) void embed_ln_kernel(
     const int* __restrict__ ids, const bf16x8* __restrict__ word, const bf16x8* __restrict__ pos,
     const bf16x8* __restrict__ type0, const float* __restrict__ gamma,
-    const float* __restrict__ beta, int T, int S, int vocab, float eps, bf16x8* __restrict__ out) {
-  const int lane = threadIdx.x & 63;
-  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (tok >= T) return;
+    const float* __restrict__ beta, int B, int S, int S_pad, int vocab, float eps,
+    bf16x8* __restrict__ out) {
+  __shared__ bf16x8 tile[KSTEPS * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tt = blockIdx.x;
   const bool act = lane < H / 8;
-  float v[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = 0.f;
+  f32x4 g0, g1, b0, b1;
   if (act) {
-    int id = ids[tok];
-    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
-    const bf16x8 w = word[(int64_t)id * (H / 8) + lane];
-    const bf16x8 p = pos[(int64_t)(tok % S) * (H / 8) + lane];
-    const bf16x8 ty = type0[lane];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = bf2f(w[i]) + bf2f(ty[i]) + bf2f(p[i]);
+    g0 = reinterpret_cast<const f32x4*>(gamma)[lane * 2];
+    g1 = reinterpret_cast<const f32x4*>(gamma)[lane * 2 + 1];
+    b0 = reinterpret_cast<const f32x4*>(beta)[lane * 2];
+    b1 = reinterpret_cast<const f32x4*>(beta)[lane * 2 + 1];
   }
-  float s = 0.f;
+  for (int i = 0; i < 8; ++i) {
+    const int r = wave * 8 + i;
+    const int tok = tt * 32 + r;
+    const int b = tok / S_pad, t = tok - b * S_pad;
+    const bool real = b < B && t < S;  // wave-uniform
+    float v[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) s += v[i];
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    if (real && act) {
+      int id = ids[(int64_t)b * S + t];
+      id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+      const bf16x8 w = word[(int64_t)id * (H / 8) + lane];
+      const bf16x8 p = pos[(int64_t)t * (H / 8) + lane];
+      const bf16x8 ty = type0[lane];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  const float mean = s * (1.0f / H);
-  float q = 0.f;
-  if (act) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) q += (v[i] - mean) * (v[i] - mean);
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-  const float rstd = rsqrtf(q * (1.0f / H) + eps);
-  if (act) {
-    f32x4 g0 = reinterpret_cast<const f32x4*>(gamma)[lane * 2], g1 = reinterpret_cast<const f32x4*>(gamma)[lane * 2 + 1];
-    f32x4 b0 = reinterpret_cast<const f32x4*>(beta)[lane * 2], b1 = reinterpret_cast<const f32x4*>(beta)[lane * 2 + 1];
-    bf16x8 o;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      o[i] = (__bf16)((v[i] - mean) * rstd * g0[i] + b0[i]);
-      o[4 + i] = (__bf16)((v[4 + i] - mean) * rstd * g1[i] + b1[i]);
+      for (int j = 0; j < 8; ++j) v[j] = bf2f(w[j]) + bf2f(ty[j]) + bf2f(p[j]);
     }
-    out[(int64_t)tok * (H / 8) + lane] = o;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s * (1.0f / H);
+    float q = 0.f;
+    if (act) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) q += (v[j] - mean) * (v[j] - mean);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q * (1.0f / H) + eps);
+    if (act) {
+      bf16x8 o = zero_bf8();  // padding positions stay exactly zero (finite keys / values)
+      if (real) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o[j] = (__bf16)((v[j] - mean) * rstd * g0[j] + b0[j]);
+          o[4 + j] = (__bf16)((v[4 + j] - mean) * rstd * g1[j] + b1[j]);
+        }
+      }
+      // columns 8 lane .. 8 lane + 7  ->  k-step lane >> 1, lane half lane & 1
+      tile[(lane >> 1) * 64 + r + 32 * (lane & 1)] = o;
+    }
   }
+  __syncthreads();
+  bf16x8* dst = out + frag_base(tt, 0, KSTEPS);
+  for (int i = threadIdx.x; i < KSTEPS * 64; i += 256) dst[i] = tile[i];
 }
 
 // ------------------------------------------------------------------------- //
-// shared pieces of the two GEMM kernels
+// shared pieces of the GEMM kernels
 // ------------------------------------------------------------------------- //
 
-// B-operand fragments of one token row: x[s] = X[tok][16s + 8h .. +7]
-__device__ inline void load_x_frags(bf16x8 (&x)[KSTEPS], const __bf16* __restrict__ row, int h,
-                                    bool valid) {
+// NS MFMAs of one weight tile held in LDS as lane-linear fragments (wl already points at this
+// lane's 16 bytes of fragment 0), against register-resident activations.  LDS reads are
+// issued one whole group of GS fragments ahead of their use so that their latency hides
+// under the previous group's MFMAs instead of stalling every second MFMA.
+template <int NS, int GS, int VALU_PER_MFMA = 0>
+__device__ inline f32x16 tile_mfma(const bf16x8* __restrict__ wl, const bf16x8 (&x)[NS], f32x16 acc) {
+  static_assert(NS % GS == 0, "group size must divide the k-steps");
+  constexpr int NG = NS / GS;
+  bf16x8 a[2][GS];
 #pragma unroll
-  for (int s = 0; s < KSTEPS; ++s) {
-    if (valid) {
-      x[s] = *reinterpret_cast<const bf16x8*>(row + 16 * s + 8 * h);
-    } else {
+  for (int i = 0; i < GS; ++i) a[0][i] = wl[i * 64];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) x[s][i] = (__bf16)0.f;
+  for (int g = 0; g < NG; ++g) {
+    if (g + 1 < NG) {
+#pragma unroll
+      for (int i = 0; i < GS; ++i) a[(g + 1) & 1][i] = wl[((g + 1) * GS + i) * 64];
+    }
+#pragma unroll
+    for (int i = 0; i < GS; ++i)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g & 1][i], x[g * GS + i], acc, 0, 0, 0);
+  }
+  // pin the pipeline in the machine scheduler (it otherwise sinks every read to just before
+  // its MFMA): reads(g0), then { reads(g+1), MFMAs(g) } ...   masks: 0x100 = DS read, 0x8 = MFMA,
+  // 0x2 = VALU.  With VALU_PER_MFMA > 0 every MFMA is followed by a slice of the caller's
+  // independent VALU work (the previous tile's epilogue), so that an in-order wave keeps the
+  // matrix pipe fed while it works through its epilogue.
+  __builtin_amdgcn_sched_group_barrier(0x100, GS, 0);
+  if (VALU_PER_MFMA == 0) {
+#pragma unroll
+    for (int g = 0; g + 1 < NG; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x100, GS, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, GS, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, GS, 0);
+  } else {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (i < NS - GS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);
     }
   }
-}
-
-// one [32 features x 384 k] weight tile: 24 MFMAs against the register-resident x
-__device__ inline f32x16 tile_mfma(const bf16x8* __restrict__ wlds, const bf16x8 (&x)[KSTEPS],
-                                   f32x16 acc, int lane) {
-#pragma unroll
-  for (int s = 0; s < KSTEPS; ++s)
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlds[s * 64 + lane], x[s], acc, 0, 0, 0);
   return acc;
 }
 
 enum { EPI_QKV = 0, EPI_GELU = 1 };
 
 struct GemmK384Params {
-  const __bf16* x;       // [T, 384] row-major
+  const bf16x8* x;       // fragment-order [T_pad, 384]
   const bf16x8* w;       // tiled [N/32][24][64] fragments
   const float* bias;     // [N]
-  int T;
-  int N;                 // multiple of 32
-  int S;                 // sequence length (QKV epilogue)
+  int N;                 // multiple of 32, >= 64, <= 1536
+  int nkt;               // S_pad / 32: token tiles per sequence (QKV epilogue)
   float q_scale;         // folded into Q: log2(e) / sqrt(32)
-  __bf16* out;           // GELU: [T, N] row-major
-  __bf16* q;             // QKV: [B, 12, S, 32]
-  __bf16* k;             //      [B, 12, S, 32]
-  __bf16* vt;            //      [B, 12, 32, S]
+  __bf16* out;           // GELU: fragment-order [T_pad, N]
+  __bf16* q;             // QKV: per (batch, head) fragment-order [S_pad, 32]
+  __bf16* k;
+  __bf16* v;
 };
 
+// epilogue of one finished 32-feature tile
+template <int EPI>
+__device__ inline void gemm_k384_epilogue(const GemmK384Params& p, const float* __restrict__ bias_lds,
+                                          const f32x16& acc, int nt, int tt, int r, int h) {
+  f32x4 v[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(bias_lds + nt * 32 + 8 * g + 4 * h);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[g][e] = acc[4 * g + e] + b[e];
+  }
+  if (EPI == EPI_GELU) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[g][e] = gelu_erf(v[g][e]);
+    store_tile_frag(p.out + frag_base(tt, 2 * nt, p.N / 16) * 8, v, r, h);
+  } else {
+    const int which = nt / NH;  // 0 = Q, 1 = K, 2 = V; one tile == one head (32 dims)
+    const int head = nt - which * NH;
+    if (which == 0) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[g][e] *= p.q_scale;
+    }
+    const int b_idx = tt / p.nkt, kt = tt - b_idx * p.nkt;
+    __bf16* base = which == 0 ? p.q : (which == 1 ? p.k : p.v);
+    store_tile_frag(base + frag_base((int64_t)(b_idx * NH + head) * p.nkt + kt, 0, 2) * 8, v, r, h);
+  }
+}
+
 // K = 384 GEMM, activations stationary in registers, weight tiles streamed through LDS.
-// Workgroup = 8 waves = 256 tokens; wave w owns tokens 32w..32w+31 of the block.
+// Workgroup = 8 waves = 256 tokens; wave w owns token tile 8 blockIdx + w.  The bias vector
+// sits in LDS, so the tile loop issues no global load besides the weight staging and the
+// epilogue stores are never waited on; the epilogue of tile nt-1 shares a basic block with
+// the MFMAs of tile nt and issues in the shadow of the matrix pipe.
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_k384_kernel(GemmK384Params p) {
   __shared__ bf16x8 wlds[2][WTILE_VEC];  // 2 x 24 KiB
+  __shared__ __attribute__((aligned(16))) float bias_lds[FF];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  const int tok = blockIdx.x * 256 + wave * 32 + r;
-  const bool valid = tok < p.T;
+  const int tt = blockIdx.x * 8 + wave;
 
   bf16x8 x[KSTEPS];
-  load_x_frags(x, p.x + (int64_t)(valid ? tok : 0) * H, h, valid);
+  {
+    const bf16x8* xs = p.x + frag_base(tt, 0, KSTEPS) + lane;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) x[s] = xs[s * 64];
+  }
+  for (int i = tid; i < p.N; i += 512) bias_lds[i] = p.bias[i];
 
   const int n_tiles = p.N / 32;
-  // prologue: stage tile 0
-  {
-    const bf16x8* src = p.w;
+  bf16x8 stage[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) wlds[0][tid + 512 * i] = src[tid + 512 * i];
-  }
+  for (int i = 0; i < 3; ++i) wlds[0][tid + 512 * i] = p.w[tid + 512 * i];
   __syncthreads();
 
-  for (int nt = 0; nt < n_tiles; ++nt) {
+  // tile 0 (nothing to overlap with yet)
+#pragma unroll
+  for (int i = 0; i < 3; ++i) stage[i] = p.w[WTILE_VEC + tid + 512 * i];
+  f32x16 prev = tile_mfma<KSTEPS, 8>(wlds[0] + lane, x, zero16());
+#pragma unroll
+  for (int i = 0; i < 3; ++i) wlds[1][tid + 512 * i] = stage[i];
+  __syncthreads();
+
+  for (int nt = 1; nt < n_tiles; ++nt) {
     const int cur = nt & 1;
-    bf16x8 stage[3];
     const bool more = nt + 1 < n_tiles;
     if (more) {
       const bf16x8* src = p.w + (int64_t)(nt + 1) * WTILE_VEC;
 #pragma unroll
       for (int i = 0; i < 3; ++i) stage[i] = src[tid + 512 * i];
     }
-    f32x16 acc = tile_mfma(wlds[cur], x, zero16(), lane);
+    const f32x16 acc = tile_mfma<KSTEPS, 8>(wlds[cur] + lane, x, zero16());
+    gemm_k384_epilogue<EPI>(p, bias_lds, prev, nt - 1, tt, r, h);
     if (more) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) wlds[cur ^ 1][tid + 512 * i] = stage[i];
     }
-
-    // epilogue: lane = token, acc[4g + e] = feature 32nt + 8g + 4h + e
-    if (valid) {
-      if (EPI == EPI_GELU) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = nt * 32 + 8 * g + 4 * h;
-          const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
-          f32x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(acc[4 * g + e] + b[e]);
-          *reinterpret_cast<bf16x4*>(p.out + (int64_t)tok * p.N + n) = __builtin_convertvector(v, bf16x4);
-        }
-      } else {
-        const int which = nt / NH;  // 0 = Q, 1 = K, 2 = V; one tile == one head (32 dims)
-        const int head = nt - which * NH;
-        const int b_idx = tok / p.S, s_idx = tok - b_idx * p.S;
-        const int64_t bh = (int64_t)b_idx * NH + head;
-        if (which < 2) {
-          __bf16* dst = (which == 0 ? p.q : p.k) + (bh * p.S + s_idx) * DH;
-          const float sc = which == 0 ? p.q_scale : 1.0f;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int d = 8 * g + 4 * h;
-            const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + nt * 32 + d);
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (acc[4 * g + e] + b[e]) * sc;
-            *reinterpret_cast<bf16x4*>(dst + d) = __builtin_convertvector(v, bf16x4);
-          }
-        } else {
-          __bf16* dst = p.vt + bh * DH * p.S + s_idx;
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int d = 8 * g + 4 * h + e;
-              dst[(int64_t)d * p.S] = (__bf16)(acc[4 * g + e] + p.bias[nt * 32 + d]);
-            }
-        }
-      }
-    }
+    prev = acc;
     __syncthreads();
   }
+  gemm_k384_epilogue<EPI>(p, bias_lds, prev, n_tiles - 1, tt, r, h);
 }
 
 struct GemmN384Params {
-  const __bf16* x;        // [T, 384 * KC] row-major
-  const bf16x8* w;        // tiled [12][24 * KC][64] fragments
+  const bf16x8* x;        // fragment-order [T_pad, 192 * KC2]
+  const bf16x8* w;        // tiled [12][12 * KC2][64] fragments
   const float* bias;      // [384]
-  const __bf16* resid;    // [T, 384]
+  const __bf16* resid;    // fragment-order [T_pad, 384]
   const float* gamma;
   const float* beta;
   float eps;
-  int T;
-  __bf16* out;            // [T, 384]
+  __bf16* out;            // fragment-order [T_pad, 384]
 };
 
-// N = 384 GEMM (K = 384 * KC) with fused bias + residual + LayerNorm epilogue.
-// Workgroup = 4 waves = 128 tokens; every wave keeps all 12 output tiles (its 32 tokens'
-// complete rows) in 192 accumulator registers, so LayerNorm never leaves the lane pair.
-template <int KC>
-__global__ __launch_bounds__(256) void gemm_n384_ln_kernel(GemmN384Params p) {
-  __shared__ bf16x8 wlds[2][WTILE_VEC];
+constexpr int KS2 = 12;                  // k-steps of one 192-wide K chunk
+constexpr int HTILE_VEC = 32 * 192 / 8;  // bf16x8 vectors of one [32 x 192] weight half-tile (12 KiB)
+
+// N = 384 GEMM (K = 192 * KC2) with fused bias + residual + LayerNorm epilogue.
+// Workgroup = 8 waves = 128 tokens: wave = (token tile tg, feature half nh); each wave
+// accumulates its 6 output tiles (192 features of its tokens) in 96 registers, the LayerNorm
+// statistics of the two halves meet through 2 KiB of LDS.  K is walked in 192-wide chunks so
+// that activations (48 VGPRs) + accumulators + fragment prefetch fit 2 waves/SIMD.
+template <int KC2>
+__global__ __launch_bounds__(512) void gemm_n384_ln_kernel(GemmN384Params p) {
+  // per buffer: [feature half][2 tiles][768 vectors] = 48 KiB
+  __shared__ bf16x8 wlds[2][2][2][HTILE_VEC];
+  __shared__ float2 stats[128][2];
+  __shared__ __attribute__((aligned(16))) float par_lds[3][H];  // bias, gamma, beta
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tg = wave & 3, nh = wave >> 2;
   const int r = lane & 31, h = lane >> 5;
-  const int tok = blockIdx.x * 128 + wave * 32 + r;
-  const bool valid = tok < p.T;
-  constexpr int KTOT = KSTEPS * KC;  // k-steps per output tile
-  constexpr int NT = H / 32;         // 12
+  const int tt = blockIdx.x * 4 + tg;
+  constexpr int KTOT = KS2 * KC2;  // k-steps per output tile
+  constexpr int NIT = KC2 * 3;     // iterations: (K chunk, pair of tiles)
 
-  f32x16 acc[NT];
+  f32x16 acc[6];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) acc[nt] = zero16();
-
-  // weight tile (nt, kc) = fragments [nt][24kc .. 24kc+23]
-  auto tile_src = [&](int it) {
-    const int kc = it / NT, nt = it - kc * NT;
-    return p.w + ((int64_t)nt * KTOT + KSTEPS * kc) * 64;
-  };
-  {
-    const bf16x8* src = tile_src(0);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) wlds[0][tid + 256 * i] = src[tid + 256 * i];
+  for (int j = 0; j < 6; ++j) acc[j] = zero16();
+  for (int i = tid; i < H; i += 512) {
+    par_lds[0][i] = p.bias[i];
+    par_lds[1][i] = p.gamma[i];
+    par_lds[2][i] = p.beta[i];
   }
+
+  // iteration it = (kc, jp): every feature half stages its tiles 6 nh + 2 jp + {0, 1}, K chunk kc.
+  // 4 half-tiles x 768 vectors = 3072 vectors = 6 per thread.
+  auto stage_src = [&](int it, int idx) {
+    const int kc = it / 3, jp = it - kc * 3;
+    const int half = idx / (2 * HTILE_VEC), rem = idx - half * (2 * HTILE_VEC);
+    const int t2 = rem / HTILE_VEC, off = rem - t2 * HTILE_VEC;
+    const int nt = half * 6 + jp * 2 + t2;
+    return p.w + ((int64_t)nt * KTOT + KS2 * kc) * 64 + off;
+  };
+  bf16x8 stage[6];
+  bf16x8* const lds_flat0 = &wlds[0][0][0][0];
+  bf16x8* const lds_flat1 = &wlds[1][0][0][0];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) lds_flat0[tid + 512 * i] = *stage_src(0, tid + 512 * i);
   __syncthreads();
 
+  const bf16x8* xs = p.x + frag_base(tt, 0, KTOT) + lane;
 #pragma unroll
-  for (int kc = 0; kc < KC; ++kc) {
-    // compiler-only barrier: keep the next chunk's 96 registers of activation loads from
-    // being hoisted above the previous chunk's MFMAs (the file is already full)
+  for (int kc = 0; kc < KC2; ++kc) {
+    // compiler-only barrier: keep this chunk's activation loads below the previous chunk's MFMAs
     asm volatile("" ::: "memory");
-    bf16x8 x[KSTEPS];
-    load_x_frags(x, p.x + (int64_t)(valid ? tok : 0) * (H * KC) + H * kc, h, valid);
+    bf16x8 x[KS2];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int it = kc * NT + nt;
+    for (int s = 0; s < KS2; ++s) x[s] = xs[(KS2 * kc + s) * 64];
+#pragma unroll
+    for (int jp = 0; jp < 3; ++jp) {
+      const int it = kc * 3 + jp;
       const int cur = it & 1;
-      bf16x8 stage[6];
-      const bool more = it + 1 < KC * NT;
+      const bool more = it + 1 < NIT;
       if (more) {
-        const bf16x8* src = tile_src(it + 1);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) stage[i] = src[tid + 256 * i];
+        for (int i = 0; i < 6; ++i) stage[i] = *stage_src(it + 1, tid + 512 * i);
       }
-      acc[nt] = tile_mfma(wlds[cur], x, acc[nt], lane);
+      acc[2 * jp] = tile_mfma<KS2, 4>(&wlds[cur][nh][0][0] + lane, x, acc[2 * jp]);
+      acc[2 * jp + 1] = tile_mfma<KS2, 4>(&wlds[cur][nh][1][0] + lane, x, acc[2 * jp + 1]);
       if (more) {
+        bf16x8* dst = cur ? lds_flat0 : lds_flat1;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) wlds[cur ^ 1][tid + 256 * i] = stage[i];
+        for (int i = 0; i < 6; ++i) dst[tid + 512 * i] = stage[i];
       }
       __syncthreads();
     }
   }
 
-  // epilogue: v = acc + bias + residual; LayerNorm over the 384 features of the token,
-  // 192 of which live in this lane and 192 in lane ^ 32
+  // epilogue: v = acc + bias + residual; LayerNorm over the token's 384 features, of which
+  // this lane holds 96, lane ^ 32 another 96 and the partner wave (other nh) the remaining 192
   asm volatile("" ::: "memory");
-  const __bf16* res = p.resid + (int64_t)(valid ? tok : 0) * H;
-  float sum = 0.f;
+  const __bf16* res = p.resid + frag_base(tt, 0, KSTEPS) * 8;
+  float sum = 0.f, sq = 0.f;
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
+  for (int j = 0; j < 6; ++j) {
+    const int nt = nh * 6 + j;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int n = nt * 32 + 8 * g + 4 * h;
-      const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
-      const bf16x4 rr = *reinterpret_cast<const bf16x4*>(res + n);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(&par_lds[0][nt * 32 + 8 * g + 4 * h]);
+      const bf16x4 rr = *reinterpret_cast<const bf16x4*>(
+          res + ((int64_t)((2 * nt + (g >> 1)) * 64 + r + 32 * (g & 1))) * 8 + 4 * h);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float v = acc[nt][4 * g + e] + b[e] + bf2f(rr[e]);
-        acc[nt][4 * g + e] = v;
+        const float v = acc[j][4 * g + e] + b[e] + bf2f(rr[e]);
+        acc[j][4 * g + e] = v;
         sum += v;
+        sq = fmaf(v, v, sq);
       }
     }
+  }
   sum += __shfl_xor(sum, 32);
-  const float mean = sum * (1.0f / H);
-  float sq = 0.f;
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float d = acc[nt][i] - mean;
-      sq += d * d;
-    }
   sq += __shfl_xor(sq, 32);
-  const float rstd = rsqrtf(sq * (1.0f / H) + p.eps);
-  if (valid) {
-    __bf16* dst = p.out + (int64_t)tok * H;
+  if (h == 0) stats[tg * 32 + r][nh] = make_float2(sum, sq);
+  __syncthreads();
+  const float2 s0 = stats[tg * 32 + r][0], s1 = stats[tg * 32 + r][1];
+  const float mean = (s0.x + s1.x) * (1.0f / H);
+  const float var = fmaxf((s0.y + s1.y) * (1.0f / H) - mean * mean, 0.f);
+  const float rstd = rsqrtf(var + p.eps);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+  for (int j = 0; j < 6; ++j) {
+    const int nt = nh * 6 + j;
+    f32x4 v[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = nt * 32 + 8 * g + 4 * h;
-        const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + n);
-        const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + n);
-        f32x4 v;
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(&par_lds[1][nt * 32 + 8 * g + 4 * h]);
+      const f32x4 be = *reinterpret_cast<const f32x4*>(&par_lds[2][nt * 32 + 8 * g + 4 * h]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (acc[nt][4 * g + e] - mean) * rstd * ga[e] + be[e];
-        *reinterpret_cast<bf16x4*>(dst + n) = __builtin_convertvector(v, bf16x4);
-      }
+      for (int e = 0; e < 4; ++e) v[g][e] = (acc[j][4 * g + e] - mean) * rstd * ga[e] + be[e];
+    }
+    store_tile_frag(p.out + frag_base(tt, 2 * nt, KSTEPS) * 8, v, r, h);
   }
 }
 
 // ------------------------------------------------------------------------- //
-// attention: one workgroup per (batch row, head, block of 256 queries)
+// fused MLP: X2 = LN(X1 + gelu(X1 W1^T + b1) W2^T + b2) without the [T, 1536] round trip
+// ------------------------------------------------------------------------- //
+struct MlpParams {
+  const bf16x8* x1;      // fragment-order [T_pad, 384]: GEMM input and residual
+  const bf16x8* w1;      // tiled [48][24][64]: chunk c = features 32c..32c+31 of W1 [1536, 384]
+  const float* b1;       // [1536]
+  const bf16x8* w2c;     // chunk-major [48][12][2][64]: W2[32 nt + r][32 c + 16 s2 + 8 h + j]
+  const float* b2;       // [384]
+  const float* gamma;
+  const float* beta;
+  float eps;
+  __bf16* out;           // fragment-order [T_pad, 384]
+};
+
+constexpr int MLP_CHUNKS = FF / 32;  // 48
+
+#ifdef SSKD_PROBE
+// diagnostic build only (tools/mlp_probe.hip): s_memtime stamps of workgroup 0, waves 0 and 4
+__device__ unsigned long long g_probe[2][64][4];
+#define SSKD_STAMP(role, it, slot)                                                         \
+  do {                                                                                     \
+    if (blockIdx.x == 0 && tg == 0 && (it) < 64) {                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                   \
+      unsigned long long t_ = __builtin_amdgcn_s_memtime();                                \
+      __builtin_amdgcn_s_waitcnt(0xC07F);                                                  \
+      if (lane == 0) g_probe[role][it][slot] = t_;                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                   \
+    }                                                                                      \
+  } while (0)
+#else
+#define SSKD_STAMP(role, it, slot) do {} while (0)
+#endif
+
+// Workgroup = 8 waves = 128 tokens.  Waves 0-3 are PRODUCERS, waves 4-7 CONSUMERS; wave w and
+// w + 4 own the same 32-token tile and (waves of a workgroup are dealt to SIMDs cyclically)
+// share a SIMD, so every SIMD runs one of each:
+//   producer, iteration i : hT = W1[chunk i] X1^T            (24 MFMAs, X1 in 96 registers)
+//                           + bias, GELU, bf16 of chunk i-1  -> 2 KiB B-operand image in LDS
+//   consumer, iteration i : Y^T[12 tiles] += W2[:, chunk i-2] hT[i-2]   (24 MFMAs, 192 accumulators)
+// One barrier per iteration.  The consumer never issues anything but LDS reads and MFMAs, so
+// the matrix pipe keeps running while the producer works through GELU; the hidden activations
+// never touch HBM.  At the end the consumer holds every feature of its tokens: bias + residual +
+// LayerNorm stay inside the lane pair.
+__global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
+  __shared__ bf16x8 w1buf[2][WTILE_VEC];          // 2 x 24 KiB
+  __shared__ bf16x8 w2buf[2][WTILE_VEC];          // 2 x 24 KiB
+  __shared__ bf16x8 hbuf[4][2][128];              // [token tile][slot][2 k-steps x 64 lanes]
+  __shared__ __attribute__((aligned(16))) float b1_lds[FF];
+  __shared__ __attribute__((aligned(16))) float par_lds[3][H];  // b2, gamma, beta
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave < 4;  // wave-uniform
+  const int tg = wave & 3;
+  const int r = lane & 31, h = lane >> 5;
+  const int tt = blockIdx.x * 4 + tg;
+
+  for (int i = tid; i < FF; i += 512) b1_lds[i] = p.b1[i];
+  for (int i = tid; i < H; i += 512) {
+    par_lds[0][i] = p.b2[i];
+    par_lds[1][i] = p.gamma[i];
+    par_lds[2][i] = p.beta[i];
+  }
+  // W1 chunk 0 for iteration 0
+  for (int i = tid; i < WTILE_VEC; i += 512) w1buf[0][i] = p.w1[i];
+  __syncthreads();
+
+  if (producer) {
+    bf16x8 x[KSTEPS];
+    {
+      const bf16x8* xs = p.x1 + frag_base(tt, 0, KSTEPS) + lane;
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) x[s] = xs[s * 64];
+    }
+    // Weight staging goes through registers (LDS-DMA was measured slower here: its 1 KiB pieces
+    // cost 100-150 issue cycles each in these in-order waves and their writes stall fragment
+    // reads) and is software-pipelined two iterations deep: the 6 loads of W1 chunk it+2 are
+    // sprinkled between this iteration's MFMAs (a burst of loads right after the barrier keeps
+    // all 8 waves stuck in the CU's 64 B/clk address path while the matrix pipe idles), travel
+    // across the barrier in registers and are written to LDS at the start of iteration it+1,
+    // one full iteration before their first use.  Consumers do the same for W2.
+    f32x16 prev = zero16();
+    bf16x8 stage[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) stage[i] = p.w1[WTILE_VEC + tid + 256 * i];  // chunk 1
+    for (int it = 0; it <= MLP_CHUNKS + 1; ++it) {
+      SSKD_STAMP(0, it, 0);
+      if (it + 1 < MLP_CHUNKS) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w1buf[(it + 1) & 1][tid + 256 * i] = stage[i];
+      }
+      // chunk it+2 (clamped: the last two iterations reload chunk 47 and never write it)
+      const bf16x8* next_src = p.w1 + (int64_t)(it + 2 < MLP_CHUNKS ? it + 2 : MLP_CHUNKS - 1) * WTILE_VEC + tid;
+      SSKD_STAMP(0, it, 1);
+      // 24 chained MFMAs of chunk `it`, with the bias + GELU + bf16 pack of chunk it-1 woven
+      // in by hand: one element after each of the first 16 MFMAs.  An in-order wave would
+      // otherwise run MFMAs and ~300 VALU instructions back to back; the hard scheduling
+      // fences keep the compiler from regrouping them.  (Edge iterations compute on zeros /
+      // write an unused image: branch-free on purpose, so the body stays one basic block.)
+      f32x16 acc = zero16();
+      {
+        const bf16x8* wl = w1buf[it & 1] + lane;
+        const int c = it >= 1 ? it - 1 : 0;
+        __bf16* hb = reinterpret_cast<__bf16*>(&hbuf[tg][c & 1][0]);
+        f32x4 bias[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          bias[g] = *reinterpret_cast<const f32x4*>(&b1_lds[c * 32 + 8 * g + 4 * h]);
+        // ring of PF + 1 registers: the read issued in slot s targets the register consumed in
+        // slot s - 1, never the one the MFMA just issued is still reading (WAR stall)
+        constexpr int PF = 6;  // fragments in flight
+        constexpr int RING = PF + 1;
+        bf16x8 a[RING];
+#pragma unroll
+#if defined(SSKD_PROBE) && SSKD_PROBE_NO_PROD_LDS
+#define SSKD_PIDX(i) 0
+#else
+#define SSKD_PIDX(i) (i)
+#endif
+        for (int i = 0; i < PF; ++i) a[i] = wl[SSKD_PIDX(i) * 64];
+        f32x4 v[4];
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s % RING], x[s], acc, 0, 0, 0);
+          if (s + PF < KSTEPS) a[(s + PF) % RING] = wl[SSKD_PIDX(s + PF) * 64];
+          if (s % 4 == 1) stage[s / 4] = next_src[256 * (s / 4)];
+          __builtin_amdgcn_sched_barrier(0);
+          if (s < 16) {
+            const int g = s >> 2, e = s & 3;
+            v[g][e] = gelu_erf(prev[s] + bias[g][e]);
+            if (e == 3)
+              *reinterpret_cast<bf16x4*>(hb + ((g >> 1) * 64 + r + 32 * (g & 1)) * 8 + 4 * h) =
+                  __builtin_convertvector(v[g], bf16x4);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      prev = acc;
+      SSKD_STAMP(0, it, 2);
+      __syncthreads();
+      SSKD_STAMP(0, it, 3);
+    }
+  } else {
+    f32x16 y[12];
+#pragma unroll
+    for (int nt = 0; nt < 12; ++nt) y[nt] = zero16();
+    const int ctid = tid - 256;
+    bf16x8 stage[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) stage[i] = zero_bf8();
+    for (int it = 0; it <= MLP_CHUNKS + 1; ++it) {
+      SSKD_STAMP(1, it, 0);
+      // W2 chunk it-1 (loaded during iteration it-1) -> LDS now, first used in iteration it+1
+      if (it >= 1 && it <= MLP_CHUNKS) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w2buf[(it - 1) & 1][ctid + 256 * i] = stage[i];
+      }
+      const bf16x8* next_src = p.w2c + (int64_t)(it < MLP_CHUNKS ? it : MLP_CHUNKS - 1) * WTILE_VEC + ctid;
+      SSKD_STAMP(1, it, 1);
+      if (it >= 2) {
+        const int c = it - 2;
+        const bf16x8* wl = w2buf[c & 1] + lane;
+        const bf16x8 hf0 = hbuf[tg][c & 1][lane], hf1 = hbuf[tg][c & 1][64 + lane];
+        // 12 output tiles x 2 k-steps; fragments of tile nt+2 are read while tile nt multiplies;
+        // one staging load of W2 chunk `it` after every second tile
+        bf16x8 a[3][2];
+        a[0][0] = wl[0];
+        a[0][1] = wl[64];
+        a[1][0] = wl[128];
+        a[1][1] = wl[192];
+#pragma unroll
+        for (int nt = 0; nt < 12; ++nt) {
+          if (nt + 2 < 12) {
+            a[(nt + 2) % 3][0] = wl[((nt + 2) * 2) * 64];
+            a[(nt + 2) % 3][1] = wl[((nt + 2) * 2 + 1) * 64];
+          }
+          y[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt % 3][0], hf0, y[nt], 0, 0, 0);
+          y[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt % 3][1], hf1, y[nt], 0, 0, 0);
+          if (nt % 2 == 1) stage[nt / 2] = next_src[256 * (nt / 2)];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) stage[i] = next_src[256 * i];
+      }
+      SSKD_STAMP(1, it, 2);
+      __syncthreads();
+      SSKD_STAMP(1, it, 3);
+    }
+
+    // epilogue: v = y + b2 + residual; LayerNorm over the token's 384 features (192 in this
+    // lane, 192 in lane ^ 32)
+    const __bf16* res = reinterpret_cast<const __bf16*>(p.x1 + frag_base(tt, 0, KSTEPS));
+    float sum = 0.f, sq = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 12; ++nt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(&par_lds[0][nt * 32 + 8 * g + 4 * h]);
+        const bf16x4 rr = *reinterpret_cast<const bf16x4*>(
+            res + ((int64_t)((2 * nt + (g >> 1)) * 64 + r + 32 * (g & 1))) * 8 + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = y[nt][4 * g + e] + b[e] + bf2f(rr[e]);
+          y[nt][4 * g + e] = v;
+          sum += v;
+          sq = fmaf(v, v, sq);
+        }
+      }
+    sum += __shfl_xor(sum, 32);
+    sq += __shfl_xor(sq, 32);
+    const float mean = sum * (1.0f / H);
+    const float var = fmaxf(sq * (1.0f / H) - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + p.eps);
+#pragma unroll
+    for (int nt = 0; nt < 12; ++nt) {
+      f32x4 v[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(&par_lds[1][nt * 32 + 8 * g + 4 * h]);
+        const f32x4 be = *reinterpret_cast<const f32x4*>(&par_lds[2][nt * 32 + 8 * g + 4 * h]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[g][e] = (y[nt][4 * g + e] - mean) * rstd * ga[e] + be[e];
+      }
+      store_tile_frag(p.out + frag_base(tt, 2 * nt, KSTEPS) * 8, v, r, h);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------- //
+// attention: one workgroup per (batch row, head), 8 waves x 32 queries per pass
 // ------------------------------------------------------------------------- //
 struct AttnParams {
-  const __bf16* q;    // [B, 12, S, 32], pre-scaled by log2(e)/sqrt(32)
-  const __bf16* k;    // [B, 12, S, 32]
-  const __bf16* vt;   // [B, 12, 32, S]
+  const bf16x8* q;    // per (b, head): fragment-order [S_pad, 32], pre-scaled by log2(e)/sqrt(32)
+  const bf16x8* k;
+  const bf16x8* v;
   const int* mask;    // [B, S] (1 = attend)
   int S;
-  __bf16* ctx;        // [B*S, 384]
+  int nkt;            // S_pad / 32
+  __bf16* ctx;        // fragment-order [T_pad, 384]
 };
 
 constexpr int ATT_MAX_S = 512;
 constexpr float MASK_NEG = -1.0e30f;
 
 __global__ __launch_bounds__(512) void attention_kernel(AttnParams p) {
-  // fragment-ordered K and V^T of this (b, head): per 32-key tile 2 + 2 fragments of 1 KiB
+  // K fragments (A operand of S^T = K Q^T: row = key, k = dim) are the stored layout as is;
+  // V^T fragments (A operand of O^T = V^T P^T: row = dim, k = key in accumulator order) are
+  // produced by transposing V through LDS.
   __shared__ bf16x8 klds[ATT_MAX_S / 32 * 2 * 64];
   __shared__ bf16x8 vlds[ATT_MAX_S / 32 * 2 * 64];
   __shared__ __attribute__((aligned(16))) float mbias[ATT_MAX_S];
@@ -382,67 +707,48 @@ __global__ __launch_bounds__(512) void attention_kernel(AttnParams p) {
   const int r = lane & 31, h = lane >> 5;
   const int bh = blockIdx.x;  // b * 12 + head
   const int b = bh / NH, head = bh - b * NH;
-  const int S = p.S;
-  const int n_ktiles = (S + 31) / 32;
-  const __bf16* kg = p.k + (int64_t)bh * S * DH;
-  const __bf16* vg = p.vt + (int64_t)bh * DH * S;
+  const int S = p.S, nkt = p.nkt;
+  const bf16x8* kg = p.k + (int64_t)bh * nkt * 128;
+  const bf16x8* vg = p.v + (int64_t)bh * nkt * 128;
 
   if (tid == 0) s_kmax = 0;
   __syncthreads();
-  // mask bias + last tile that holds an attended key
   int local_max = 0;
-  for (int i = tid; i < n_ktiles * 32; i += 512) {
+  for (int i = tid; i < nkt * 32; i += 512) {
     const bool on = i < S && p.mask[(int64_t)b * S + i] != 0;
     mbias[i] = on ? 0.f : MASK_NEG;
     if (on) local_max = i / 32 + 1;
   }
   if (local_max) atomicMax(&s_kmax, local_max);
-  // stage K fragments: A[row = key][k = dim]: lane (r, h) of step s holds K[32kt + r][16s + 8h ..+7]
-  for (int i = tid; i < n_ktiles * 2 * 64; i += 512) {
-    const int l = i & 63, s = (i >> 6) & 1, kt = i >> 7;
-    const int key = kt * 32 + (l & 31);
-    bf16x8 v;
+  for (int i = tid; i < nkt * 128; i += 512) klds[i] = kg[i];
+  // V vector i = (kt, s, lane l): V[key 32 kt + (l & 31)][dim 16 s + 8 (l >> 5) + j].
+  // Its element j belongs to V^T fragment (kt, s2 = key16 >> 4 of the tile) lane dim + 32 h',
+  // element jj, where the key's position k16 in its 16-key step gives
+  //   h' = (k16 >> 2) & 1,  jj = 4 (k16 >> 3) + (k16 & 3)      (accumulator row order)
+  {
+    __bf16* vt = reinterpret_cast<__bf16*>(vlds);
+    for (int i = tid; i < nkt * 128; i += 512) {
+      const bf16x8 v = vg[i];
+      const int l = i & 63, s = (i >> 6) & 1, kt = i >> 7;
+      const int kk = l & 31, k16 = kk & 15, s2 = kk >> 4;
+      const int hp = (k16 >> 2) & 1, jj = 4 * (k16 >> 3) + (k16 & 3);
+      const int d0 = 16 * s + 8 * (l >> 5);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
-    if (key < S) v = *reinterpret_cast<const bf16x8*>(kg + (int64_t)key * DH + 16 * s + 8 * (l >> 5));
-    klds[i] = v;
-  }
-  // stage V^T fragments: A[row = dim][k = key] in accumulator order:
-  // element j of lane (r, h), step s2 <- V^T[dim r][key 32kt + 16 s2 + 8 (j >> 2) + 4h + (j & 3)]
-  for (int i = tid; i < n_ktiles * 2 * 64; i += 512) {
-    const int l = i & 63, s2 = (i >> 6) & 1, kt = i >> 7;
-    const int d = l & 31, hh = l >> 5;
-    const int key0 = kt * 32 + 16 * s2 + 4 * hh;
-    bf16x8 v;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int key = key0 + 8 * (e >> 2) + (e & 3);
-      v[e] = key < S ? vg[(int64_t)d * S + key] : (__bf16)0.f;
+      for (int j = 0; j < 8; ++j) vt[(((kt * 2 + s2) * 64) + d0 + j + 32 * hp) * 8 + jj] = v[j];
     }
-    vlds[i] = v;
   }
   __syncthreads();
   const int kmax = s_kmax;
 
-  for (int qb = 0; qb * 256 < S; ++qb) {
-    const int qrow = qb * 256 + wave * 32 + r;
-    const bool valid = qrow < S;
-    bf16x8 qf[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      if (valid) {
-        qf[s] = *reinterpret_cast<const bf16x8*>(p.q + ((int64_t)bh * S + qrow) * DH + 16 * s + 8 * h);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) qf[s][e] = (__bf16)0.f;
-      }
-    }
+  for (int qt = wave; qt < nkt; qt += 8) {
+    const bf16x8* qg = p.q + ((int64_t)bh * nkt + qt) * 128 + lane;
+    const bf16x8 qf0 = qg[0], qf1 = qg[64];
     f32x16 o = zero16();
     float m = MASK_NEG, l = 0.f;
     for (int kt = 0; kt < kmax; ++kt) {
       f32x16 sc = zero16();
-      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(klds[(kt * 2 + 0) * 64 + lane], qf[0], sc, 0, 0, 0);
-      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(klds[(kt * 2 + 1) * 64 + lane], qf[1], sc, 0, 0, 0);
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(klds[(kt * 2 + 0) * 64 + lane], qf0, sc, 0, 0, 0);
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(klds[(kt * 2 + 1) * 64 + lane], qf1, sc, 0, 0, 0);
       // sc[4g + e] = score(key 32kt + 8g + 4h + e, query = lane), in log2 units
       float mt = MASK_NEG;
 #pragma unroll
@@ -475,16 +781,93 @@ __global__ __launch_bounds__(512) void attention_kernel(AttnParams p) {
     }
     l += __shfl_xor(l, 32);
     const float inv = l > 0.f ? 1.0f / l : 0.f;
-    if (valid) {
-      __bf16* dst = p.ctx + ((int64_t)b * S + qrow) * H + head * DH;
+    f32x4 v[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 v;
+    for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = o[4 * g + e] * inv;
-        *reinterpret_cast<bf16x4*>(dst + 8 * g + 4 * h) = __builtin_convertvector(v, bf16x4);
+      for (int e = 0; e < 4; ++e) v[g][e] = o[4 * g + e] * inv;
+    store_tile_frag(p.ctx + frag_base((int64_t)b * nkt + qt, 2 * head, KSTEPS) * 8, v, r, h);
+  }
+}
+
+// ------------------------------------------------------------------------- //
+// tail: masked mean-pool + L2 normalise straight from the fragment-order hidden states,
+// and the row-major un-tiling used by the hidden-state test hook
+// ------------------------------------------------------------------------- //
+__global__ __launch_bounds__(512) void pool_normalize_frag_kernel(const bf16x8* __restrict__ hidden,
+                                                                  const int* __restrict__ mask, int S,
+                                                                  int nkt, int normalize,
+                                                                  float* __restrict__ out) {
+  __shared__ float e_lds[H];
+  __shared__ float red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int b = blockIdx.x;
+  // wave w owns k-steps w, w + 8, w + 16; lane (r, h) accumulates over the tokens r, r + 32, ...
+  float acc[3][8];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[a][j] = 0.f;
+  float cnt = 0.f;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int t = kt * 32 + r;
+    const float w = (t < S && mask[(int64_t)b * S + t] != 0) ? 1.0f : 0.0f;
+    cnt += w;
+    if (__any(w != 0.f)) {
+      const bf16x8* src = hidden + frag_base((int64_t)b * nkt + kt, 0, KSTEPS) + lane;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const bf16x8 v = src[(wave + 8 * a) * 64];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[a][j] = fmaf(w, bf2f(v[j]), acc[a][j]);
       }
     }
+  }
+  // sum over the 32 tokens of a lane half (xor < 32 stays inside the half)
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) {
+    cnt += __shfl_xor(cnt, o);
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[a][j] += __shfl_xor(acc[a][j], o);
+  }
+  const float n = fmaxf(cnt, 1e-9f);
+  if (r == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e_lds[16 * (wave + 8 * a) + 8 * h + j] = acc[a][j] / n;
+  }
+  __syncthreads();
+  float ss = 0.f;
+  if (tid < H) ss = e_lds[tid] * e_lds[tid];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  if (lane == 0) red[wave] = ss;
+  __syncthreads();
+  if (tid < H) {
+    float e = e_lds[tid];
+    if (normalize) {
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < 6; ++w) tot += red[w];
+      e /= fmaxf(sqrtf(tot), 1e-12f);
+    }
+    out[(int64_t)b * H + tid] = e;
+  }
+}
+
+__global__ __launch_bounds__(256) void untile_hidden_kernel(const __bf16* __restrict__ frag, int B, int S,
+                                                            int nkt, __bf16* __restrict__ rows) {
+  const int64_t total = (int64_t)B * S * H;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int col = (int)(i % H);
+    const int64_t bt = i / H;
+    const int t = (int)(bt % S), b = (int)(bt / S);
+    const int64_t vec = frag_base((int64_t)b * nkt + (t >> 5), col >> 4, KSTEPS) + (t & 31) + 32 * ((col >> 3) & 1);
+    rows[i] = frag[vec * 8 + (col & 7)];
   }
 }
 
@@ -492,14 +875,21 @@ __global__ __launch_bounds__(512) void attention_kernel(AttnParams p) {
 // workspace carve-up
 // ------------------------------------------------------------------------- //
 struct Workspace {
-  __bf16 *xa, *xb, *q, *k, *vt, *ctx, *ffn;
+  __bf16 *xa, *xb, *q, *k, *v, *ctx;
   size_t bytes;
 };
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+inline int s_pad_of(int S) { return (S + 31) / 32 * 32; }
+inline int64_t t_pad_of(int B, int S) { return ((int64_t)B * s_pad_of(S) + 255) / 256 * 256; }
+
+// Token buffers hold T_pad = roundup(B * S_pad, 256) rows (no kernel bounds-checks); the
+// per-(batch, head) Q / K / V buffers get one more sequence of slack because a padding token
+// tile's batch index can run one past B.
 Workspace carve(void* base, int B, int S) {
-  const size_t T = (size_t)B * S;
+  const size_t T = (size_t)t_pad_of(B, S);
+  const size_t Sp = (size_t)s_pad_of(S);
   char* pch = static_cast<char*>(base);
   Workspace w{};
   auto take = [&](size_t elems) {
@@ -509,11 +899,10 @@ Workspace carve(void* base, int B, int S) {
   };
   w.xa = take(T * H);
   w.xb = take(T * H);
-  w.q = take(T * H);
-  w.k = take(T * H);
-  w.vt = take(T * H);
+  w.q = take((T + Sp) * H);
+  w.k = take((T + Sp) * H);
+  w.v = take((T + Sp) * H);
   w.ctx = take(T * H);
-  w.ffn = take(T * FF);
   w.bytes = (size_t)(pch - static_cast<char*>(base));
   return w;
 }
@@ -535,14 +924,15 @@ int check_cfg(const sskd_encoder_config* cfg, const sskd_encoder_weights* w, int
   return SSKD_OK;
 }
 
-// runs embeddings + all layers; returns the buffer holding the final hidden states
+// runs embeddings + all layers; returns the (fragment-order) buffer holding the final hidden states
 int run_layers(const sskd_encoder_config* cfg, const sskd_encoder_weights* w, const int32_t* d_ids,
                const int32_t* d_mask, int B, int S, const Workspace& ws, hipStream_t st,
                __bf16** final_hidden) {
-  const int T = B * S;
-  hipLaunchKernelGGL(embed_ln_kernel, dim3((T + 3) / 4), dim3(256), 0, st, d_ids,
+  const int Sp = s_pad_of(S), nkt = Sp / 32;
+  const int Tpad = (int)t_pad_of(B, S);
+  hipLaunchKernelGGL(embed_ln_kernel, dim3(Tpad / 32), dim3(256), 0, st, d_ids,
                      static_cast<const bf16x8*>(w->word_emb), static_cast<const bf16x8*>(w->pos_emb),
-                     static_cast<const bf16x8*>(w->type_emb), w->emb_ln_g, w->emb_ln_b, T, S,
+                     static_cast<const bf16x8*>(w->type_emb), w->emb_ln_g, w->emb_ln_b, B, S, Sp,
                      cfg->vocab_size, cfg->layer_norm_eps, reinterpret_cast<bf16x8*>(ws.xa));
   int rc = sskd::check_launch("embed_ln_kernel");
   if (rc != SSKD_OK) return rc;
@@ -555,65 +945,53 @@ int run_layers(const sskd_encoder_config* cfg, const sskd_encoder_weights* w, co
                      lw.w2 && lw.b2 && lw.ln2_g && lw.ln2_b,
                  "encoder: layer %d has a null weight pointer", li);
     GemmK384Params g{};
-    g.x = x;
+    g.x = reinterpret_cast<const bf16x8*>(x);
     g.w = static_cast<const bf16x8*>(lw.wqkv);
     g.bias = lw.bqkv;
-    g.T = T;
     g.N = 3 * H;
-    g.S = S;
+    g.nkt = nkt;
     g.q_scale = LOG2E / sqrtf((float)DH);
     g.q = ws.q;
     g.k = ws.k;
-    g.vt = ws.vt;
-    hipLaunchKernelGGL(gemm_k384_kernel<EPI_QKV>, dim3((T + 255) / 256), dim3(512), 0, st, g);
+    g.v = ws.v;
+    hipLaunchKernelGGL(gemm_k384_kernel<EPI_QKV>, dim3(Tpad / 256), dim3(512), 0, st, g);
     if ((rc = sskd::check_launch("gemm_k384_kernel<QKV>")) != SSKD_OK) return rc;
 
     AttnParams a{};
-    a.q = ws.q;
-    a.k = ws.k;
-    a.vt = ws.vt;
+    a.q = reinterpret_cast<const bf16x8*>(ws.q);
+    a.k = reinterpret_cast<const bf16x8*>(ws.k);
+    a.v = reinterpret_cast<const bf16x8*>(ws.v);
     a.mask = d_mask;
     a.S = S;
+    a.nkt = nkt;
     a.ctx = ws.ctx;
     hipLaunchKernelGGL(attention_kernel, dim3(B * NH), dim3(512), 0, st, a);
     if ((rc = sskd::check_launch("attention_kernel")) != SSKD_OK) return rc;
 
     GemmN384Params o{};
-    o.x = ws.ctx;
+    o.x = reinterpret_cast<const bf16x8*>(ws.ctx);
     o.w = static_cast<const bf16x8*>(lw.wo);
     o.bias = lw.bo;
     o.resid = x;
     o.gamma = lw.ln1_g;
     o.beta = lw.ln1_b;
     o.eps = cfg->layer_norm_eps;
-    o.T = T;
     o.out = x1;
-    hipLaunchKernelGGL(gemm_n384_ln_kernel<1>, dim3((T + 127) / 128), dim3(256), 0, st, o);
-    if ((rc = sskd::check_launch("gemm_n384_ln_kernel<1>")) != SSKD_OK) return rc;
+    hipLaunchKernelGGL(gemm_n384_ln_kernel<2>, dim3(Tpad / 128), dim3(512), 0, st, o);
+    if ((rc = sskd::check_launch("gemm_n384_ln_kernel<2>")) != SSKD_OK) return rc;
 
-    GemmK384Params f{};
-    f.x = x1;
-    f.w = static_cast<const bf16x8*>(lw.w1);
-    f.bias = lw.b1;
-    f.T = T;
-    f.N = FF;
-    f.S = S;
-    f.out = ws.ffn;
-    hipLaunchKernelGGL(gemm_k384_kernel<EPI_GELU>, dim3((T + 255) / 256), dim3(512), 0, st, f);
-    if ((rc = sskd::check_launch("gemm_k384_kernel<GELU>")) != SSKD_OK) return rc;
-
-    GemmN384Params d{};
-    d.x = ws.ffn;
-    d.w = static_cast<const bf16x8*>(lw.w2);
-    d.bias = lw.b2;
-    d.resid = x1;
-    d.gamma = lw.ln2_g;
-    d.beta = lw.ln2_b;
-    d.eps = cfg->layer_norm_eps;
-    d.T = T;
-    d.out = x;
-    hipLaunchKernelGGL(gemm_n384_ln_kernel<4>, dim3((T + 127) / 128), dim3(256), 0, st, d);
-    if ((rc = sskd::check_launch("gemm_n384_ln_kernel<4>")) != SSKD_OK) return rc;
+    MlpParams m{};
+    m.x1 = reinterpret_cast<const bf16x8*>(x1);
+    m.w1 = static_cast<const bf16x8*>(lw.w1);
+    m.b1 = lw.b1;
+    m.w2c = static_cast<const bf16x8*>(lw.w2);
+    m.b2 = lw.b2;
+    m.gamma = lw.ln2_g;
+    m.beta = lw.ln2_b;
+    m.eps = cfg->layer_norm_eps;
+    m.out = x;
+    hipLaunchKernelGGL(fused_mlp_ln_kernel, dim3(Tpad / 128), dim3(512), 0, st, m);
+    if ((rc = sskd::check_launch("fused_mlp_ln_kernel")) != SSKD_OK) return rc;
   }
   *final_hidden = x;
   return SSKD_OK;
@@ -629,46 +1007,61 @@ size_t sskd_encoder_workspace_bytes(const sskd_encoder_config* cfg, int B, int S
   return carve(nullptr, B, S).bytes;
 }
 
+}  // extern "C"
+
+namespace {
+
+int prepare(const sskd_encoder_config* cfg, const sskd_encoder_weights* w, int B, int S,
+            void* d_workspace, size_t workspace_bytes, Workspace* ws) {
+  int rc = check_cfg(cfg, w, B, S);
+  if (rc != SSKD_OK) return rc;
+  const size_t need = sskd_encoder_workspace_bytes(cfg, B, S);
+  if (B > 0 && (!d_workspace || workspace_bytes < need))
+    return sskd::fail(SSKD_ERR_WORKSPACE, "encoder: workspace %zu B < required %zu B",
+                      workspace_bytes, need);
+  if (B > 0) *ws = carve(d_workspace, B, S);
+  return SSKD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int sskd_encoder_hidden(const sskd_encoder_config* cfg, const sskd_encoder_weights* w,
                         const int32_t* d_ids, const int32_t* d_mask, int B, int S,
                         void* d_hidden_bf16, void* d_workspace, size_t workspace_bytes,
                         void* stream) {
-  int rc = check_cfg(cfg, w, B, S);
-  if (rc != SSKD_OK) return rc;
-  if (B == 0) return SSKD_OK;
+  Workspace ws{};
+  int rc = prepare(cfg, w, B, S, d_workspace, workspace_bytes, &ws);
+  if (rc != SSKD_OK || B == 0) return rc;
   SSKD_REQUIRE(d_ids && d_mask && d_hidden_bf16, "encoder_hidden: null pointer");
-  const size_t need = sskd_encoder_workspace_bytes(cfg, B, S);
-  if (!d_workspace || workspace_bytes < need)
-    return sskd::fail(SSKD_ERR_WORKSPACE, "encoder: workspace %zu B < required %zu B",
-                      workspace_bytes, need);
-  const Workspace ws = carve(d_workspace, B, S);
   hipStream_t st = sskd::as_stream(stream);
   __bf16* fin = nullptr;
   rc = run_layers(cfg, w, d_ids, d_mask, B, S, ws, st, &fin);
   if (rc != SSKD_OK) return rc;
-  if (hipMemcpyAsync(d_hidden_bf16, fin, (size_t)B * S * H * sizeof(__bf16),
-                     hipMemcpyDeviceToDevice, st) != hipSuccess)
-    return sskd::fail(SSKD_ERR_HIP, "encoder_hidden: copy failed");
-  return SSKD_OK;
+  const int64_t total = (int64_t)B * S * H;
+  int64_t blocks = sskd::ceil_div(total, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(untile_hidden_kernel, dim3((unsigned)blocks), dim3(256), 0, st, fin, B, S,
+                     s_pad_of(S) / 32, static_cast<__bf16*>(d_hidden_bf16));
+  return sskd::check_launch("untile_hidden_kernel");
 }
 
 int sskd_encoder_forward(const sskd_encoder_config* cfg, const sskd_encoder_weights* w,
                          const int32_t* d_ids, const int32_t* d_mask, int B, int S, int normalize,
                          float* d_out, void* d_workspace, size_t workspace_bytes, void* stream) {
-  int rc = check_cfg(cfg, w, B, S);
-  if (rc != SSKD_OK) return rc;
-  if (B == 0) return SSKD_OK;
+  Workspace ws{};
+  int rc = prepare(cfg, w, B, S, d_workspace, workspace_bytes, &ws);
+  if (rc != SSKD_OK || B == 0) return rc;
   SSKD_REQUIRE(d_ids && d_mask && d_out, "encoder_forward: null pointer");
-  const size_t need = sskd_encoder_workspace_bytes(cfg, B, S);
-  if (!d_workspace || workspace_bytes < need)
-    return sskd::fail(SSKD_ERR_WORKSPACE, "encoder: workspace %zu B < required %zu B",
-                      workspace_bytes, need);
-  const Workspace ws = carve(d_workspace, B, S);
   hipStream_t st = sskd::as_stream(stream);
   __bf16* fin = nullptr;
   rc = run_layers(cfg, w, d_ids, d_mask, B, S, ws, st, &fin);
   if (rc != SSKD_OK) return rc;
-  return sskd_pool_normalize(fin, 1, d_mask, B, S, normalize, d_out, stream);
+  hipLaunchKernelGGL(pool_normalize_frag_kernel, dim3(B), dim3(512), 0, st,
+                     reinterpret_cast<const bf16x8*>(fin), d_mask, S, s_pad_of(S) / 32, normalize,
+                     d_out);
+  return sskd::check_launch("pool_normalize_frag_kernel");
 }
 
 }  // extern "C"

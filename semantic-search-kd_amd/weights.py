@@ -152,6 +152,17 @@ def tile_weight_fragments(w: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(t.reshape(n // 32, k // 16, 64, 8))
 
 
+def tile_w2_chunked(w2: np.ndarray) -> np.ndarray:
+    """``W2[384, 1536]`` -> ``[48 chunks][12 tiles][2 k-steps][64 lanes][8]`` for the fused MLP: the
+    consumer waves' A operand for hidden chunk ``c`` (features 32c..32c+31), lane ``l`` holding
+    ``W2[32 nt + (l & 31)][32 c + 16 s2 + 8 (l >> 5) + j]`` (csrc/encoder.hip fused_mlp_ln_kernel)."""
+    n, k = w2.shape
+    assert n % 32 == 0 and k % 32 == 0, (n, k)
+    t = w2.reshape(n // 32, 32, k // 32, 2, 2, 8)   # [nt, r, c, s2, h, j]
+    t = t.transpose(2, 0, 3, 4, 1, 5)               # [c, nt, s2, h, r, j] -> lane = 32 h + r
+    return np.ascontiguousarray(t.reshape(k // 32, n // 32, 2, 64, 8))
+
+
 def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
     """Round-to-nearest-even fp32 -> bf16 bit pattern (uint16)."""
     u = np.ascontiguousarray(x, np.float32).view(np.uint32)
@@ -209,7 +220,7 @@ class DeviceWeights:
             lw.ln1_b = f32(sd[p + "attention.output.LayerNorm.bias"])
             lw.w1 = bf16(tile_weight_fragments(sd[p + "intermediate.dense.weight"]))
             lw.b1 = f32(sd[p + "intermediate.dense.bias"])
-            lw.w2 = bf16(tile_weight_fragments(sd[p + "output.dense.weight"]))
+            lw.w2 = bf16(tile_w2_chunked(sd[p + "output.dense.weight"]))
             lw.b2 = f32(sd[p + "output.dense.bias"])
             lw.ln2_g = f32(sd[p + "output.LayerNorm.weight"])
             lw.ln2_b = f32(sd[p + "output.LayerNorm.bias"])
