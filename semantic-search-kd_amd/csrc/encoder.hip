@@ -79,6 +79,18 @@ __device__ inline float gelu_erf(float x) {
   return fmaf(fabsf(hx), erf_abs, hx);
 }
 
+// Exchange with lane ^ 32 in the VALU (v_permlane32_swap) instead of __shfl_xor's ds_bpermute,
+// which is an LDS round trip in the middle of a dependency chain.  After the swap r[0] / r[1]
+// hold {own, partner} in some order on every lane, so symmetric reductions need no select.
+__device__ inline float pair_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ inline float pair_sum(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // first vector (lane 0) of fragment (token tile tt, k-step s) of an activation with KS k-steps
 __device__ inline int64_t frag_base(int64_t tt, int s, int KS) { return (tt * KS + s) * 64; }
 
@@ -425,8 +437,8 @@ __global__ __launch_bounds__(512) void gemm_n384_ln_kernel(GemmN384Params p) {
       }
     }
   }
-  sum += __shfl_xor(sum, 32);
-  sq += __shfl_xor(sq, 32);
+  sum = pair_sum(sum);
+  sq = pair_sum(sq);
   if (h == 0) stats[tg * 32 + r][nh] = make_float2(sum, sq);
   __syncthreads();
   const float2 s0 = stats[tg * 32 + r][0], s1 = stats[tg * 32 + r][1];
@@ -658,8 +670,8 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
           sq = fmaf(v, v, sq);
         }
       }
-    sum += __shfl_xor(sum, 32);
-    sq += __shfl_xor(sq, 32);
+    sum = pair_sum(sum);
+    sq = pair_sum(sq);
     const float mean = sum * (1.0f / H);
     const float var = fmaxf(sq * (1.0f / H) - mean * mean, 0.f);
     const float rstd = rsqrtf(var + p.eps);
@@ -698,10 +710,14 @@ __global__ __launch_bounds__(512) void attention_kernel(AttnParams p) {
   // K fragments (A operand of S^T = K Q^T: row = key, k = dim) are the stored layout as is;
   // V^T fragments (A operand of O^T = V^T P^T: row = dim, k = key in accumulator order) are
   // produced by transposing V through LDS.
-  __shared__ bf16x8 klds[ATT_MAX_S / 32 * 2 * 64];
-  __shared__ bf16x8 vlds[ATT_MAX_S / 32 * 2 * 64];
-  __shared__ __attribute__((aligned(16))) float mbias[ATT_MAX_S];
+  // dynamic LDS sized for this sequence length (33 KiB at S = 256, so 4 workgroups fit a CU and
+  // one workgroup's K / V staging overlaps the others' compute): [K frags][V^T frags][mask bias]
+  extern __shared__ __attribute__((aligned(16))) unsigned char att_lds[];
+  bf16x8* const klds = reinterpret_cast<bf16x8*>(att_lds);
+  bf16x8* const vlds = klds + p.nkt * 128;
+  float* const mbias = reinterpret_cast<float*>(vlds + p.nkt * 128);
   __shared__ int s_kmax;
+  __shared__ int s_partial[ATT_MAX_S / 32];  // key tile holds at least one masked key
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -712,12 +728,14 @@ __global__ __launch_bounds__(512) void attention_kernel(AttnParams p) {
   const bf16x8* vg = p.v + (int64_t)bh * nkt * 128;
 
   if (tid == 0) s_kmax = 0;
+  if (tid < ATT_MAX_S / 32) s_partial[tid] = 0;
   __syncthreads();
   int local_max = 0;
   for (int i = tid; i < nkt * 32; i += 512) {
     const bool on = i < S && p.mask[(int64_t)b * S + i] != 0;
     mbias[i] = on ? 0.f : MASK_NEG;
     if (on) local_max = i / 32 + 1;
+    else s_partial[i / 32] = 1;
   }
   if (local_max) atomicMax(&s_kmax, local_max);
   for (int i = tid; i < nkt * 128; i += 512) klds[i] = kg[i];
@@ -750,36 +768,41 @@ __global__ __launch_bounds__(512) void attention_kernel(AttnParams p) {
       sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(klds[(kt * 2 + 0) * 64 + lane], qf0, sc, 0, 0, 0);
       sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(klds[(kt * 2 + 1) * 64 + lane], qf1, sc, 0, 0, 0);
       // sc[4g + e] = score(key 32kt + 8g + 4h + e, query = lane), in log2 units
-      float mt = MASK_NEG;
+      if (s_partial[kt]) {  // workgroup-uniform: only tiles with masked / padding keys pay for the bias
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 mb = *reinterpret_cast<const f32x4*>(&mbias[kt * 32 + 8 * g + 4 * h]);
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 mb = *reinterpret_cast<const f32x4*>(&mbias[kt * 32 + 8 * g + 4 * h]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          sc[4 * g + e] += mb[e];
-          mt = fmaxf(mt, sc[4 * g + e]);
+          for (int e = 0; e < 4; ++e) sc[4 * g + e] += mb[e];
         }
       }
-      mt = fmaxf(mt, __shfl_xor(mt, 32));
-      const float m_new = fmaxf(m, mt);
-      const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+      float mt = sc[0];
+#pragma unroll
+      for (int i = 1; i < 16; ++i) mt = fmaxf(mt, sc[i]);
+      mt = pair_max(mt);
+      if (__any(mt > m)) {
+        // the running maximum moves (rare after the first tiles): rescale what is accumulated
+        const float m_new = fmaxf(m, mt);
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+        l *= alpha;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[i] *= alpha;
+        m = m_new;
+      }
       float ps = 0.f;
       bf16x8 pf[2];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float e = __builtin_amdgcn_exp2f(sc[i] - m_new);
+        const float e = __builtin_amdgcn_exp2f(sc[i] - m);
         ps += e;
         pf[i >> 3][i & 7] = (__bf16)e;
       }
-      l = l * alpha + ps;
-      m = m_new;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) o[i] *= alpha;
+      l += ps;
       // O^T[dim, query] += V^T[dim, key] P^T[key, query]; P^T is the accumulator as B operand
       o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vlds[(kt * 2 + 0) * 64 + lane], pf[0], o, 0, 0, 0);
       o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vlds[(kt * 2 + 1) * 64 + lane], pf[1], o, 0, 0, 0);
     }
-    l += __shfl_xor(l, 32);
+    l = pair_sum(l);
     const float inv = l > 0.f ? 1.0f / l : 0.f;
     f32x4 v[4];
 #pragma unroll
@@ -965,7 +988,10 @@ int run_layers(const sskd_encoder_config* cfg, const sskd_encoder_weights* w, co
     a.S = S;
     a.nkt = nkt;
     a.ctx = ws.ctx;
-    hipLaunchKernelGGL(attention_kernel, dim3(B * NH), dim3(512), 0, st, a);
+    const size_t att_lds_bytes = (size_t)nkt * (2 * 128 * sizeof(bf16x8) + 32 * sizeof(float));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)att_lds_bytes);
+    hipLaunchKernelGGL(attention_kernel, dim3(B * NH), dim3(512), att_lds_bytes, st, a);
     if ((rc = sskd::check_launch("attention_kernel")) != SSKD_OK) return rc;
 
     GemmN384Params o{};

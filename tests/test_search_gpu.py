@@ -267,3 +267,38 @@ def test_full_size_properties_1m(gpu, native_lib):
     # idempotence: a second search returns the same bits
     s2, i2 = b.search_device(queries, k)
     assert np.array_equal(s2.cpu().numpy(), s) and np.array_equal(i2.cpu().numpy(), i)
+
+
+def test_cfg3_full_corpus_8_8m_rows(gpu, native_lib):
+    """BASELINE cfg 3 size on one GPU: 8 841 823 rows (13.6 GB in HBM), checked bit-exact against the
+    oracle on a handful of queries, plus one shard of the 8-way split with its id offset."""
+    n = 8_841_823
+    gen = torch.Generator(device="cuda").manual_seed(1234)
+    b = FAISSIndexBuilder(embedding_dim=384, metric="ip")
+    b.reserve(n)
+    host_chunks = []
+    for lo in range(0, n, 1 << 20):
+        hi = min(lo + (1 << 20), n)
+        rows = torch.randn((hi - lo, 384), generator=gen, device="cuda", dtype=torch.float32)
+        rows /= rows.norm(dim=1, keepdim=True)
+        b.add(rows)
+        host_chunks.append(rows.cpu().numpy())
+    assert b.index.ntotal == n
+    corpus = np.concatenate(host_chunks)
+    del host_chunks
+    q = oracle.seeded_unit_rows(6, 384, 77)
+    q[0] = corpus[n - 1]          # the very last row (ragged final tile) must be retrievable
+    q[1] = corpus[4_420_911]
+    D, I = b.search(q, k=10)
+    ref_s, ref_i = oracle.topk_fma(q, corpus, 10)
+    assert np.array_equal(I, ref_i) and np.array_equal(D, ref_s)
+    assert I[0, 0] == n - 1 and I[1, 0] == 4_420_911
+    # shard 7 of 8 (1 105 227 rows, SURVEY.md §8d) with global ids
+    from semantic_search_kd_amd.dist import shard_bounds
+
+    lo, hi = shard_bounds(n, 8, 7)
+    shard = FAISSIndexBuilder(embedding_dim=384, metric="ip", id_offset=lo)
+    shard.add(torch.from_numpy(corpus[lo:hi]).cuda())
+    Ds, Is = shard.search(q, k=10)
+    ref_s, ref_i = oracle.topk_fma(q, corpus[lo:hi], 10, id_offset=lo)
+    assert np.array_equal(Is, ref_i) and np.array_equal(Ds, ref_s) and Is.min() >= lo
