@@ -548,11 +548,11 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
     for (int i = 0; i < 6; ++i) stage[i] = p.w1[WTILE_VEC + tid + 256 * i];  // chunk 1
     for (int it = 0; it <= MLP_CHUNKS + 1; ++it) {
       SSKD_STAMP(0, it, 0);
-      if (it + 1 < MLP_CHUNKS) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) w1buf[(it + 1) & 1][tid + 256 * i] = stage[i];
-      }
-      // chunk it+2 (clamped: the last two iterations reload chunk 47 and never write it)
+      // stage[i] holds W1 chunk it+1 (loaded during iteration it-1): it is written to LDS and
+      // immediately reloaded with chunk it+2, one vector every fourth MFMA slot, so neither the
+      // LDS-fill nor the load issue ever forms a burst.  (Edge iterations write a buffer nobody
+      // reads and reload the clamped last chunk: branch-free.)
+      bf16x8* const stage_dst = w1buf[(it + 1) & 1] + tid;
       const bf16x8* next_src = p.w1 + (int64_t)(it + 2 < MLP_CHUNKS ? it + 2 : MLP_CHUNKS - 1) * WTILE_VEC + tid;
       SSKD_STAMP(0, it, 1);
       // 24 chained MFMAs of chunk `it`, with the bias + GELU + bf16 pack of chunk it-1 woven
@@ -586,7 +586,10 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
         for (int s = 0; s < KSTEPS; ++s) {
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s % RING], x[s], acc, 0, 0, 0);
           if (s + PF < KSTEPS) a[(s + PF) % RING] = wl[SSKD_PIDX(s + PF) * 64];
-          if (s % 4 == 1) stage[s / 4] = next_src[256 * (s / 4)];
+          if (s % 4 == 1) {
+            stage_dst[256 * (s / 4)] = stage[s / 4];
+            stage[s / 4] = next_src[256 * (s / 4)];
+          }
           __builtin_amdgcn_sched_barrier(0);
           if (s < 16) {
             const int g = s >> 2, e = s & 3;
@@ -613,11 +616,11 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
     for (int i = 0; i < 6; ++i) stage[i] = zero_bf8();
     for (int it = 0; it <= MLP_CHUNKS + 1; ++it) {
       SSKD_STAMP(1, it, 0);
-      // W2 chunk it-1 (loaded during iteration it-1) -> LDS now, first used in iteration it+1
-      if (it >= 1 && it <= MLP_CHUNKS) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) w2buf[(it - 1) & 1][ctid + 256 * i] = stage[i];
-      }
+      // stage[i] holds W2 chunk it-1 (loaded during iteration it-1): written to w2buf[(it-1)&1]
+      // (first used in iteration it+1) and reloaded with chunk `it`, one vector after every second
+      // output tile.  In iteration 0 the write lands in the buffer of chunk 1, before anything
+      // real is stored there.
+      bf16x8* const stage_dst = w2buf[(it + 1) & 1] + ctid;
       const bf16x8* next_src = p.w2c + (int64_t)(it < MLP_CHUNKS ? it : MLP_CHUNKS - 1) * WTILE_VEC + ctid;
       SSKD_STAMP(1, it, 1);
       if (it >= 2) {
@@ -639,12 +642,18 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
           }
           y[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt % 3][0], hf0, y[nt], 0, 0, 0);
           y[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt % 3][1], hf1, y[nt], 0, 0, 0);
-          if (nt % 2 == 1) stage[nt / 2] = next_src[256 * (nt / 2)];
+          if (nt % 2 == 1) {
+            stage_dst[256 * (nt / 2)] = stage[nt / 2];
+            stage[nt / 2] = next_src[256 * (nt / 2)];
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) stage[i] = next_src[256 * i];
+        for (int i = 0; i < 6; ++i) {
+          stage_dst[256 * i] = stage[i];
+          stage[i] = next_src[256 * i];
+        }
       }
       SSKD_STAMP(1, it, 2);
       __syncthreads();

@@ -121,6 +121,7 @@ struct ScanParams {
   int* part_ids;
   const float* ub_scores;  // chained pass: exclusive upper bound per query
   const int* ub_ids;
+  int* tau;                // shared per-query threshold (monotone int image of a float), see below
   int64_t n_rows;
   int n_tiles;
   int nq;
@@ -133,6 +134,29 @@ struct ScanParams {
 __device__ inline bool ranks_before(float sa, int ia, float sb, int ib) {
   return sa > sb || (sa == sb && ia < ib);
 }
+
+// Shared threshold.  Every per-lane list that is full holds K distinct rows scoring >= its K-th
+// entry, so that entry is a lower bound on the query's final K-th score: any row scoring STRICTLY
+// less can never reach the result and need not enter any list.  The bound is shared across all
+// lanes / waves / workgroups of a query through one word per query updated with atomicMax on a
+// monotone integer image of the float.  Reads may be stale (per-XCD L2s are not coherent): a stale
+// value is a smaller bound, i.e. less pruning, never a wrong result.  Rows scoring exactly the
+// bound are kept (they may still win on the id tie-break).
+__device__ inline int float_to_ordered(float x) {
+  const int b = __float_as_int(x);
+  return b >= 0 ? b : b ^ 0x7FFFFFFF;
+}
+__device__ inline float ordered_to_float(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF); }
+constexpr int TAU_REFRESH_TILES = 8;  // re-read the shared bound every this many tiles
+
+#ifdef SSKD_PROBE
+// diagnostic build only (tools/scan_probe.hip): [0] tiles, [1] slow-path entries, [2] per-register
+// insertion blocks executed, [3] lane insertions, [4] threshold publications
+__device__ unsigned long long g_scan_probe[8];
+#define SSKD_COUNT(i, n) do { const unsigned long long n_ = (unsigned long long)(n); if ((threadIdx.x & 63) == 0) atomicAdd(&g_scan_probe[i], n_); } while (0)
+#else
+#define SSKD_COUNT(i, n) do {} while (0)
+#endif
 
 template <int K>
 struct LaneList {
@@ -212,8 +236,13 @@ __global__ __launch_bounds__(WAVES * 64) void scan_topk_kernel(ScanParams p) {
   LaneList<K> list[QB];
   float ub_s[QB];
   int ub_i[QB];
+  float gthr[QB];  // last seen value of the shared threshold
+  int* tau_q[QB];
 #pragma unroll
   for (int qq = 0; qq < QB; ++qq) {
+    gthr[qq] = -INFINITY;
+    const int qg = q0 + qq * 32 + j;
+    tau_q[qq] = p.tau + (qg < p.nq ? qg : p.nq - 1);
     list[qq].clear();
     ub_s[qq] = INFINITY;
     ub_i[qq] = -1;
@@ -232,8 +261,15 @@ __global__ __launch_bounds__(WAVES * 64) void scan_topk_kernel(ScanParams p) {
   int t = t_begin + wave;
   if (t < t_end) load_group(bufA, lane_base + (int64_t)t * TILE_FLOATS);
 
-  for (; t < t_end; t += WAVES) {
+  int tiles_done = 0;
+  for (; t < t_end; t += WAVES, ++tiles_done) {
     const float* tile = lane_base + (int64_t)t * TILE_FLOATS;
+    if (tiles_done % TAU_REFRESH_TILES == 0) {
+      // fresh read of the shared bound (an atomic executes at the memory side)
+#pragma unroll
+      for (int qq = 0; qq < QB; ++qq)
+        gthr[qq] = fmaxf(gthr[qq], ordered_to_float(atomicMax(tau_q[qq], (int)0x80000000)));
+    }
     f32x16 acc[QB];
 #pragma unroll
     for (int qq = 0; qq < QB; ++qq)
@@ -267,16 +303,30 @@ __global__ __launch_bounds__(WAVES * 64) void scan_topk_kernel(ScanParams p) {
       float m = acc[qq][0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[qq][r]);
-      if (__any(m > list[qq].s[K - 1])) {
+      SSKD_COUNT(0, 1);
+      if (__any(m > list[qq].s[K - 1] && m >= gthr[qq])) {
+        SSKD_COUNT(1, 1);
+        bool grew = false;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float x = acc[qq][r];
           const int xid = rowbase + (r & 3) + 8 * (r >> 2);
-          bool take = x > list[qq].s[K - 1];
+          bool take = x > list[qq].s[K - 1] && x >= gthr[qq];
           if (HAS_UB) take = take && ranks_before(ub_s[qq], ub_i[qq], x, xid);
           if (__any(take)) {
-            if (take) list[qq].insert(x, xid);
+            SSKD_COUNT(2, 1);
+            SSKD_COUNT(3, __popcll(__ballot(take)));
+            if (take) {
+              list[qq].insert(x, xid);
+              grew = true;
+            }
           }
+        }
+        // publish this list's K-th entry (once it exists) and pick up everybody else's
+        if (grew && list[qq].s[K - 1] > -INFINITY) {
+          SSKD_COUNT(4, __popcll(__ballot(true)));
+          const int old = atomicMax(tau_q[qq], float_to_ordered(list[qq].s[K - 1]));
+          gthr[qq] = fmaxf(gthr[qq], fmaxf(ordered_to_float(old), list[qq].s[K - 1]));
         }
       }
     }
@@ -384,6 +434,11 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(MergeParams<IdT> p) {
     p.ub_scores[q] = last_s;
     p.ub_ids[q] = (int)last_i;
   }
+}
+
+__global__ __launch_bounds__(256) void fill_int_kernel(int* p, int n, int v) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = v;
 }
 
 __global__ __launch_bounds__(256) void fill_empty_kernel(float* s, int64_t* ids, int64_t n) {
@@ -555,7 +610,7 @@ size_t sskd_index_search_workspace_bytes(int64_t n_rows, int nq, int k) {
   if (n_rows < 0 || nq <= 0 || k <= 0) return 0;
   const Plan pl = make_plan(n_rows, nq, k);
   return align256(pl.part_elems * sizeof(float)) + align256(pl.part_elems * sizeof(int)) +
-         align256((size_t)nq * sizeof(float)) + align256((size_t)nq * sizeof(int));
+         align256((size_t)nq * sizeof(float)) + 2 * align256((size_t)nq * sizeof(int));
 }
 
 int sskd_index_search_plan(int64_t n_rows, int nq, int k, int* queries_per_block,
@@ -610,6 +665,8 @@ int sskd_index_search_profiled(const float* d_tiled, int64_t n_rows, const float
   float* ub_scores = reinterpret_cast<float*>(ws);
   ws += align256((size_t)nq * sizeof(float));
   int* ub_ids = reinterpret_cast<int*>(ws);
+  ws += align256((size_t)nq * sizeof(int));
+  int* tau = reinterpret_cast<int*>(ws);
 
   ScanParams sp{};
   sp.tiled = d_tiled;
@@ -618,6 +675,7 @@ int sskd_index_search_profiled(const float* d_tiled, int64_t n_rows, const float
   sp.part_ids = part_ids;
   sp.ub_scores = ub_scores;
   sp.ub_ids = ub_ids;
+  sp.tau = tau;
   sp.n_rows = n_rows;
   sp.n_tiles = pl.n_tiles;
   sp.nq = nq;
@@ -626,6 +684,8 @@ int sskd_index_search_profiled(const float* d_tiled, int64_t n_rows, const float
   sp.lists_per_query = pl.lists_per_query;
 
   for (int pass = 0; pass < pl.passes; ++pass) {
+    hipLaunchKernelGGL(fill_int_kernel, dim3((unsigned)sskd::ceil_div(nq, 256)), dim3(256), 0, st, tau,
+                       nq, (int)0x80000000);
     if (pass == 0 && ev_scan_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_scan_begin), st);
     int rc = pass == 0 ? dispatch_scan<false>(pl, sp, st) : dispatch_scan<true>(pl, sp, st);
     if (pass == 0 && ev_scan_end) (void)hipEventRecord(static_cast<hipEvent_t>(ev_scan_end), st);
