@@ -23,8 +23,7 @@
 // multiple of 256 rows so that no kernel needs a bounds check.
 //
 // Kernels per layer (hidden 384, 12 heads x 32, FFN 1536):
-//   gemm_k384_kernel<QKV>   X -> Q (pre-scaled by log2(e)/sqrt(32)), K, V per (batch, head)
-//   attention_kernel        softmax(Q K^T / sqrt(32) + mask) V          -> ctx
+//   qkv_attention_kernel    ctx = softmax((X Wq^T)(X Wk^T)^T / sqrt(32) + mask)(X Wv^T)   (Q, K, V stay on chip)
 //   gemm_n384_ln_kernel<2>  X1 = LN(X  + ctx Wo^T + bo)
 //   fused_mlp_ln_kernel     X2 = LN(X1 + gelu(X1 W1^T + b1) W2^T + b2)   (hidden 1536 stays on chip)
 #include "common.h"
@@ -94,14 +93,37 @@ __device__ inline float pair_sum(float x) {
 // first vector (lane 0) of fragment (token tile tt, k-step s) of an activation with KS k-steps
 __device__ inline int64_t frag_base(int64_t tt, int s, int KS) { return (tt * KS + s) * 64; }
 
-// Store the 16 accumulator values of a finished 32-feature tile in fragment order: lane (r, h)
-// holds features 8g + 4h + e (g, e = 0..3) of token r, i.e. elements 4h..4h+3 of lane
-// r + 32 (g & 1) of k-step 2 nt + (g >> 1).  `dst` points at fragment (tt, 2 nt) lane 0.
-__device__ inline void store_tile_frag(__bf16* __restrict__ dst, const f32x4 (&v)[4], int r, int h) {
+// Store the 16 accumulator values of a finished 32-feature tile in fragment order.  Lane (r, h)
+// holds features 8g + 4h + e (g, e = 0..3) of token r, i.e. HALF of each of the four 16-byte
+// fragment slots of its token.  One v_permlane32_swap per dword trades halves inside the lane
+// pair (r, 0) <-> (r, 1): afterwards lane l owns the complete slot l of k-step 2 nt (from groups
+// g = 0, 1) and of k-step 2 nt + 1 (g = 2, 3), so the tile leaves as two fully linear 1 KiB
+// dwordx4 stores.  `dst` points at fragment (tt, 2 nt) lane 0.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ inline void store_tile_frag(__bf16* __restrict__ dst, const f32x4 (&v)[4], int lane) {
+  u32x2 d[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    __bf16* p = dst + ((int64_t)((g >> 1) * 64 + r + 32 * (g & 1))) * 8 + 4 * h;
-    *reinterpret_cast<bf16x4*>(p) = __builtin_convertvector(v[g], bf16x4);
+    const bf16x4 o = __builtin_convertvector(v[g], bf16x4);
+    d[g] = __builtin_bit_cast(u32x2, o);
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    // swap(a = d[2s], b = d[2s+1]): lanes < 32 end up with (own a, partner's a) = features 0..7 of
+    // the step, lanes >= 32 with (partner's b, own b) = features 8..15
+    const auto w0 = __builtin_amdgcn_permlane32_swap(d[2 * s][0], d[2 * s + 1][0], false, false);
+    const auto w1 = __builtin_amdgcn_permlane32_swap(d[2 * s][1], d[2 * s + 1][1], false, false);
+    u32x4 out;
+    out[0] = w0[0];
+    out[1] = w1[0];
+    out[2] = w0[1];
+    out[3] = w1[1];
+#if defined(SSKD_PROBE) && SSKD_PROBE_NOSTORE
+    asm volatile("" ::"v"(out));
+#else
+    *reinterpret_cast<u32x4*>(dst + ((int64_t)(s * 64 + lane)) * 8) = out;
+#endif
   }
 }
 
@@ -222,110 +244,6 @@ __device__ inline f32x16 tile_mfma(const bf16x8* __restrict__ wl, const bf16x8 (
     }
   }
   return acc;
-}
-
-enum { EPI_QKV = 0, EPI_GELU = 1 };
-
-struct GemmK384Params {
-  const bf16x8* x;       // fragment-order [T_pad, 384]
-  const bf16x8* w;       // tiled [N/32][24][64] fragments
-  const float* bias;     // [N]
-  int N;                 // multiple of 32, >= 64, <= 1536
-  int nkt;               // S_pad / 32: token tiles per sequence (QKV epilogue)
-  float q_scale;         // folded into Q: log2(e) / sqrt(32)
-  __bf16* out;           // GELU: fragment-order [T_pad, N]
-  __bf16* q;             // QKV: per (batch, head) fragment-order [S_pad, 32]
-  __bf16* k;
-  __bf16* v;
-};
-
-// epilogue of one finished 32-feature tile
-template <int EPI>
-__device__ inline void gemm_k384_epilogue(const GemmK384Params& p, const float* __restrict__ bias_lds,
-                                          const f32x16& acc, int nt, int tt, int r, int h) {
-  f32x4 v[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const f32x4 b = *reinterpret_cast<const f32x4*>(bias_lds + nt * 32 + 8 * g + 4 * h);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[g][e] = acc[4 * g + e] + b[e];
-  }
-  if (EPI == EPI_GELU) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[g][e] = gelu_erf(v[g][e]);
-    store_tile_frag(p.out + frag_base(tt, 2 * nt, p.N / 16) * 8, v, r, h);
-  } else {
-    const int which = nt / NH;  // 0 = Q, 1 = K, 2 = V; one tile == one head (32 dims)
-    const int head = nt - which * NH;
-    if (which == 0) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[g][e] *= p.q_scale;
-    }
-    const int b_idx = tt / p.nkt, kt = tt - b_idx * p.nkt;
-    __bf16* base = which == 0 ? p.q : (which == 1 ? p.k : p.v);
-    store_tile_frag(base + frag_base((int64_t)(b_idx * NH + head) * p.nkt + kt, 0, 2) * 8, v, r, h);
-  }
-}
-
-// K = 384 GEMM, activations stationary in registers, weight tiles streamed through LDS.
-// Workgroup = 8 waves = 256 tokens; wave w owns token tile 8 blockIdx + w.  The bias vector
-// sits in LDS, so the tile loop issues no global load besides the weight staging and the
-// epilogue stores are never waited on; the epilogue of tile nt-1 shares a basic block with
-// the MFMAs of tile nt and issues in the shadow of the matrix pipe.
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_k384_kernel(GemmK384Params p) {
-  __shared__ bf16x8 wlds[2][WTILE_VEC];  // 2 x 24 KiB
-  __shared__ __attribute__((aligned(16))) float bias_lds[FF];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, h = lane >> 5;
-  const int tt = blockIdx.x * 8 + wave;
-
-  bf16x8 x[KSTEPS];
-  {
-    const bf16x8* xs = p.x + frag_base(tt, 0, KSTEPS) + lane;
-#pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) x[s] = xs[s * 64];
-  }
-  for (int i = tid; i < p.N; i += 512) bias_lds[i] = p.bias[i];
-
-  const int n_tiles = p.N / 32;
-  bf16x8 stage[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) wlds[0][tid + 512 * i] = p.w[tid + 512 * i];
-  __syncthreads();
-
-  // tile 0 (nothing to overlap with yet)
-#pragma unroll
-  for (int i = 0; i < 3; ++i) stage[i] = p.w[WTILE_VEC + tid + 512 * i];
-  f32x16 prev = tile_mfma<KSTEPS, 8>(wlds[0] + lane, x, zero16());
-#pragma unroll
-  for (int i = 0; i < 3; ++i) wlds[1][tid + 512 * i] = stage[i];
-  __syncthreads();
-
-  for (int nt = 1; nt < n_tiles; ++nt) {
-    const int cur = nt & 1;
-    const bool more = nt + 1 < n_tiles;
-    if (more) {
-      const bf16x8* src = p.w + (int64_t)(nt + 1) * WTILE_VEC;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) stage[i] = src[tid + 512 * i];
-    }
-    const f32x16 acc = tile_mfma<KSTEPS, 8>(wlds[cur] + lane, x, zero16());
-    gemm_k384_epilogue<EPI>(p, bias_lds, prev, nt - 1, tt, r, h);
-    if (more) {
-#pragma unroll
-      for (int i = 0; i < 3; ++i) wlds[cur ^ 1][tid + 512 * i] = stage[i];
-    }
-    prev = acc;
-    __syncthreads();
-  }
-  gemm_k384_epilogue<EPI>(p, bias_lds, prev, n_tiles - 1, tt, r, h);
 }
 
 struct GemmN384Params {
@@ -456,7 +374,7 @@ __global__ __launch_bounds__(512) void gemm_n384_ln_kernel(GemmN384Params p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[g][e] = (acc[j][4 * g + e] - mean) * rstd * ga[e] + be[e];
     }
-    store_tile_frag(p.out + frag_base(tt, 2 * nt, KSTEPS) * 8, v, r, h);
+    store_tile_frag(p.out + frag_base(tt, 2 * nt, KSTEPS) * 8, v, lane);
   }
 }
 
@@ -694,47 +612,62 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[g][e] = (y[nt][4 * g + e] - mean) * rstd * ga[e] + be[e];
       }
-      store_tile_frag(p.out + frag_base(tt, 2 * nt, KSTEPS) * 8, v, r, h);
+      store_tile_frag(p.out + frag_base(tt, 2 * nt, KSTEPS) * 8, v, lane);
     }
   }
 }
 
-// ------------------------------------------------------------------------- //
-// attention: one workgroup per (batch row, head), 8 waves x 32 queries per pass
-// ------------------------------------------------------------------------- //
-struct AttnParams {
-  const bf16x8* q;    // per (b, head): fragment-order [S_pad, 32], pre-scaled by log2(e)/sqrt(32)
-  const bf16x8* k;
-  const bf16x8* v;
-  const int* mask;    // [B, S] (1 = attend)
-  int S;
-  int nkt;            // S_pad / 32
-  __bf16* ctx;        // fragment-order [T_pad, 384]
-};
-
 constexpr int ATT_MAX_S = 512;
 constexpr float MASK_NEG = -1.0e30f;
 
-__global__ __launch_bounds__(512) void attention_kernel(AttnParams p) {
-  // K fragments (A operand of S^T = K Q^T: row = key, k = dim) are the stored layout as is;
-  // V^T fragments (A operand of O^T = V^T P^T: row = dim, k = key in accumulator order) are
-  // produced by transposing V through LDS.
-  // dynamic LDS sized for this sequence length (33 KiB at S = 256, so 4 workgroups fit a CU and
-  // one workgroup's K / V staging overlaps the others' compute): [K frags][V^T frags][mask bias]
-  extern __shared__ __attribute__((aligned(16))) unsigned char att_lds[];
-  bf16x8* const klds = reinterpret_cast<bf16x8*>(att_lds);
+// ------------------------------------------------------------------------- //
+// fused QKV projection + attention: ctx = softmax((X Wq^T)(X Wk^T)^T / sqrt(32) + mask) (X Wv^T)
+// one workgroup per (batch row, head); Q, K, V never reach HBM
+// ------------------------------------------------------------------------- //
+struct QkvAttnParams {
+  const bf16x8* x;      // fragment-order [T_pad, 384]
+  const bf16x8* wqkv;   // tiled [36][24][64]: tile h = Wq head h, 12 + h = Wk, 24 + h = Wv
+  const float* bqkv;    // [1152]
+  const int* mask;      // [B, S]
+  int B;
+  int S;
+  int nkt;              // S_pad / 32
+  int hpw;              // heads per workgroup (divides 12)
+  float q_scale;        // log2(e) / sqrt(32)
+  __bf16* ctx;          // fragment-order [T_pad, 384]
+};
+
+// Phase 1 (projection), wave = one 32-token tile at a time, activations in 96 registers:
+//   Q^T = Wq X^T   accumulators [dim, query]: packed, they ARE the B operand of S^T = K Q^T
+//   K^T = Wk X^T   accumulators [dim, key], key on the lane: packed, they ARE K's A-operand
+//                  fragments (rows = keys, k = dims in the same accumulator order as Q^T)
+//   V   = X Wv^T   (operands swapped) accumulators [key, dim], dim on the lane: packed, they ARE
+//                  the A-operand fragments of O^T = V^T P^T (rows = dims, k = keys in accumulator
+//                  order, the order P^T's accumulators have) - no transpose anywhere.
+// K and V fragments go to LDS (every wave needs every key), Q stays in registers.
+// Phase 2: flash-style attention per query tile, online softmax lane-local (query on the lane).
+// TWO_TILES = sequences longer than 256 tokens: every wave owns two query tiles and re-reads their
+// activations per head (192 resident registers would not fit); otherwise one tile, read once.
+template <bool TWO_TILES>
+__global__ __launch_bounds__(512) void qkv_attention_kernel(QkvAttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char qa_lds[];
+  // [3 weight tiles: 72 KiB][K frags nkt*2 KiB][V frags nkt*2 KiB][mask bias nkt*32 f32][bias 96 f32]
+  bf16x8* const wlds = reinterpret_cast<bf16x8*>(qa_lds);
+  bf16x8* const klds = wlds + 3 * WTILE_VEC;
   bf16x8* const vlds = klds + p.nkt * 128;
   float* const mbias = reinterpret_cast<float*>(vlds + p.nkt * 128);
+  float* const bias_lds = mbias + p.nkt * 32;
   __shared__ int s_kmax;
-  __shared__ int s_partial[ATT_MAX_S / 32];  // key tile holds at least one masked key
+  __shared__ int s_partial[ATT_MAX_S / 32];
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  const int bh = blockIdx.x;  // b * 12 + head
-  const int b = bh / NH, head = bh - b * NH;
+  // One workgroup = one batch row x `hpw` consecutive heads (hpw = 12 when there are enough rows
+  // to fill the chip: the row's activations are then read once and stay in registers).
+  const int groups = NH / p.hpw;
+  const int b = blockIdx.x / groups, head0 = (blockIdx.x - b * groups) * p.hpw;
   const int S = p.S, nkt = p.nkt;
-  const bf16x8* kg = p.k + (int64_t)bh * nkt * 128;
-  const bf16x8* vg = p.v + (int64_t)bh * nkt * 128;
 
   if (tid == 0) s_kmax = 0;
   if (tid < ATT_MAX_S / 32) s_partial[tid] = 0;
@@ -747,78 +680,141 @@ __global__ __launch_bounds__(512) void attention_kernel(AttnParams p) {
     else s_partial[i / 32] = 1;
   }
   if (local_max) atomicMax(&s_kmax, local_max);
-  for (int i = tid; i < nkt * 128; i += 512) klds[i] = kg[i];
-  // V vector i = (kt, s, lane l): V[key 32 kt + (l & 31)][dim 16 s + 8 (l >> 5) + j].
-  // Its element j belongs to V^T fragment (kt, s2 = key16 >> 4 of the tile) lane dim + 32 h',
-  // element jj, where the key's position k16 in its 16-key step gives
-  //   h' = (k16 >> 2) & 1,  jj = 4 (k16 >> 3) + (k16 & 3)      (accumulator row order)
-  {
-    __bf16* vt = reinterpret_cast<__bf16*>(vlds);
-    for (int i = tid; i < nkt * 128; i += 512) {
-      const bf16x8 v = vg[i];
-      const int l = i & 63, s = (i >> 6) & 1, kt = i >> 7;
-      const int kk = l & 31, k16 = kk & 15, s2 = kk >> 4;
-      const int hp = (k16 >> 2) & 1, jj = 4 * (k16 >> 3) + (k16 & 3);
-      const int d0 = 16 * s + 8 * (l >> 5);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) vt[(((kt * 2 + s2) * 64) + d0 + j + 32 * hp) * 8 + jj] = v[j];
-    }
-  }
-  __syncthreads();
-  const int kmax = s_kmax;
 
-  for (int qt = wave; qt < nkt; qt += 8) {
-    const bf16x8* qg = p.q + ((int64_t)bh * nkt + qt) * 128 + lane;
-    const bf16x8 qf0 = qg[0], qf1 = qg[64];
-    f32x16 o = zero16();
-    float m = MASK_NEG, l = 0.f;
-    for (int kt = 0; kt < kmax; ++kt) {
-      f32x16 sc = zero16();
-      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(klds[(kt * 2 + 0) * 64 + lane], qf0, sc, 0, 0, 0);
-      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(klds[(kt * 2 + 1) * 64 + lane], qf1, sc, 0, 0, 0);
-      // sc[4g + e] = score(key 32kt + 8g + 4h + e, query = lane), in log2 units
-      if (s_partial[kt]) {  // workgroup-uniform: only tiles with masked / padding keys pay for the bias
+  // activations of this wave's token tile: resident for every head (single-tile case)
+  bf16x8 x0[KSTEPS];
+  if (!TWO_TILES) {
+    const int tq = wave < nkt ? wave : 0;
+    const bf16x8* xs = p.x + frag_base((int64_t)b * nkt + tq, 0, KSTEPS) + lane;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 mb = *reinterpret_cast<const f32x4*>(&mbias[kt * 32 + 8 * g + 4 * h]);
+    for (int s = 0; s < KSTEPS; ++s) x0[s] = xs[s * 64];
+  }
+
+  // the three weight tiles of a head = 4608 vectors = 9 per thread; staged through registers so
+  // that head + 1 is already in flight while head is being processed
+  bf16x8 wstage[9];
+  auto load_weights = [&](int head) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) sc[4 * g + e] += mb[e];
+    for (int i = 0; i < 9; ++i) {
+      const int v = tid + 512 * i;
+      const int which = v / WTILE_VEC, off = v - which * WTILE_VEC;
+      wstage[i] = p.wqkv[(int64_t)(which * NH + head) * WTILE_VEC + off];
+    }
+  };
+  load_weights(head0);
+
+  for (int hi = 0; hi < p.hpw; ++hi) {
+    const int head = head0 + hi;
+    __syncthreads();  // previous head: every wave is done with the weights and with K / V
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wlds[tid + 512 * i] = wstage[i];
+    if (tid < 96) bias_lds[tid] = p.bqkv[(tid >> 5) * H + head * DH + (tid & 31)];
+    __syncthreads();
+    if (hi + 1 < p.hpw) load_weights(head + 1);
+
+    // ---- phase 1: projection of this wave's token tiles ------------------------------------
+    bf16x8 qf[2][2];  // Q^T fragments of up to two query tiles (S <= 512)
+    auto project = [&](const bf16x8 (&x)[KSTEPS], int u, int tq) {
+      f32x16 aq = tile_mfma<KSTEPS, 4>(wlds + lane, x, zero16());
+      f32x16 ak = tile_mfma<KSTEPS, 4>(wlds + WTILE_VEC + lane, x, zero16());
+      // V with the operands swapped: A = activations (row = token), B = weights (col = dim)
+      f32x16 av = zero16();
+      {
+        const bf16x8* wv = wlds + 2 * WTILE_VEC + lane;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+          av = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[s], wv[s * 64], av, 0, 0, 0);
+      }
+      // Q^T / K^T: lane = token, acc[4g + e] = dim 8g + 4h + e.  V: lane = dim, acc = keys.
+      bf16x8 kf[2], vf[2];
+      const float bv = bias_lds[64 + r];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(&bias_lds[8 * g + 4 * h]);
+        const f32x4 bk = *reinterpret_cast<const f32x4*>(&bias_lds[32 + 8 * g + 4 * h]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = 4 * g + e;
+          qf[u][i >> 3][i & 7] = (__bf16)((aq[i] + bq[e]) * p.q_scale);
+          kf[i >> 3][i & 7] = (__bf16)(ak[i] + bk[e]);
+          vf[i >> 3][i & 7] = (__bf16)(av[i] + bv);
         }
       }
-      float mt = sc[0];
+      klds[(tq * 2 + 0) * 64 + lane] = kf[0];
+      klds[(tq * 2 + 1) * 64 + lane] = kf[1];
+      vlds[(tq * 2 + 0) * 64 + lane] = vf[0];
+      vlds[(tq * 2 + 1) * 64 + lane] = vf[1];
+    };
+    if (!TWO_TILES) {
+      if (wave < nkt) project(x0, 0, wave);
+    } else {
 #pragma unroll
-      for (int i = 1; i < 16; ++i) mt = fmaxf(mt, sc[i]);
-      mt = pair_max(mt);
-      if (__any(mt > m)) {
-        // the running maximum moves (rare after the first tiles): rescale what is accumulated
-        const float m_new = fmaxf(m, mt);
-        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-        l *= alpha;
+      for (int u = 0; u < 2; ++u) {
+        const int tq = wave + 8 * u;
+        if (tq < nkt) {
+          const bf16x8* xs = p.x + frag_base((int64_t)b * nkt + tq, 0, KSTEPS) + lane;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) o[i] *= alpha;
-        m = m_new;
+          for (int s = 0; s < KSTEPS; ++s) x0[s] = xs[s * 64];
+          project(x0, u, tq);
+        }
       }
-      float ps = 0.f;
-      bf16x8 pf[2];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float e = __builtin_amdgcn_exp2f(sc[i] - m);
-        ps += e;
-        pf[i >> 3][i & 7] = (__bf16)e;
-      }
-      l += ps;
-      // O^T[dim, query] += V^T[dim, key] P^T[key, query]; P^T is the accumulator as B operand
-      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vlds[(kt * 2 + 0) * 64 + lane], pf[0], o, 0, 0, 0);
-      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vlds[(kt * 2 + 1) * 64 + lane], pf[1], o, 0, 0, 0);
     }
-    l = pair_sum(l);
-    const float inv = l > 0.f ? 1.0f / l : 0.f;
-    f32x4 v[4];
+    __syncthreads();
+    const int kmax = s_kmax;
+
+    // ---- phase 2: attention -------------------------------------------------------------------
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int u = 0; u < (TWO_TILES ? 2 : 1); ++u) {
+      const int qt = wave + 8 * u;
+      if (qt >= nkt) break;
+      const bf16x8 qf0 = qf[u][0], qf1 = qf[u][1];
+      f32x16 o = zero16();
+      float m = MASK_NEG, l = 0.f;
+      for (int kt = 0; kt < kmax; ++kt) {
+        f32x16 sc = zero16();
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(klds[(kt * 2 + 0) * 64 + lane], qf0, sc, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(klds[(kt * 2 + 1) * 64 + lane], qf1, sc, 0, 0, 0);
+        if (s_partial[kt]) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[g][e] = o[4 * g + e] * inv;
-    store_tile_frag(p.ctx + frag_base((int64_t)b * nkt + qt, 2 * head, KSTEPS) * 8, v, r, h);
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 mb = *reinterpret_cast<const f32x4*>(&mbias[kt * 32 + 8 * g + 4 * h]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sc[4 * g + e] += mb[e];
+          }
+        }
+        float mt = sc[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mt = fmaxf(mt, sc[i]);
+        mt = pair_max(mt);
+        if (__any(mt > m)) {
+          const float m_new = fmaxf(m, mt);
+          const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+          l *= alpha;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) o[i] *= alpha;
+          m = m_new;
+        }
+        float ps = 0.f;
+        bf16x8 pf[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float e = __builtin_amdgcn_exp2f(sc[i] - m);
+          ps += e;
+          pf[i >> 3][i & 7] = (__bf16)e;
+        }
+        l += ps;
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vlds[(kt * 2 + 0) * 64 + lane], pf[0], o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vlds[(kt * 2 + 1) * 64 + lane], pf[1], o, 0, 0, 0);
+      }
+      l = pair_sum(l);
+      const float inv = l > 0.f ? 1.0f / l : 0.f;
+      f32x4 v[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[g][e] = o[4 * g + e] * inv;
+      store_tile_frag(p.ctx + frag_base((int64_t)b * nkt + qt, 2 * head, KSTEPS) * 8, v, lane);
+    }
   }
 }
 
@@ -907,7 +903,7 @@ __global__ __launch_bounds__(256) void untile_hidden_kernel(const __bf16* __rest
 // workspace carve-up
 // ------------------------------------------------------------------------- //
 struct Workspace {
-  __bf16 *xa, *xb, *q, *k, *v, *ctx;
+  __bf16 *xa, *xb, *ctx;
   size_t bytes;
 };
 
@@ -916,12 +912,9 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline int s_pad_of(int S) { return (S + 31) / 32 * 32; }
 inline int64_t t_pad_of(int B, int S) { return ((int64_t)B * s_pad_of(S) + 255) / 256 * 256; }
 
-// Token buffers hold T_pad = roundup(B * S_pad, 256) rows (no kernel bounds-checks); the
-// per-(batch, head) Q / K / V buffers get one more sequence of slack because a padding token
-// tile's batch index can run one past B.
+// Token buffers hold T_pad = roundup(B * S_pad, 256) rows (no kernel bounds-checks).
 Workspace carve(void* base, int B, int S) {
   const size_t T = (size_t)t_pad_of(B, S);
-  const size_t Sp = (size_t)s_pad_of(S);
   char* pch = static_cast<char*>(base);
   Workspace w{};
   auto take = [&](size_t elems) {
@@ -931,9 +924,6 @@ Workspace carve(void* base, int B, int S) {
   };
   w.xa = take(T * H);
   w.xb = take(T * H);
-  w.q = take((T + Sp) * H);
-  w.k = take((T + Sp) * H);
-  w.v = take((T + Sp) * H);
   w.ctx = take(T * H);
   w.bytes = (size_t)(pch - static_cast<char*>(base));
   return w;
@@ -976,32 +966,26 @@ int run_layers(const sskd_encoder_config* cfg, const sskd_encoder_weights* w, co
     SSKD_REQUIRE(lw.wqkv && lw.bqkv && lw.wo && lw.bo && lw.ln1_g && lw.ln1_b && lw.w1 && lw.b1 &&
                      lw.w2 && lw.b2 && lw.ln2_g && lw.ln2_b,
                  "encoder: layer %d has a null weight pointer", li);
-    GemmK384Params g{};
-    g.x = reinterpret_cast<const bf16x8*>(x);
-    g.w = static_cast<const bf16x8*>(lw.wqkv);
-    g.bias = lw.bqkv;
-    g.N = 3 * H;
-    g.nkt = nkt;
-    g.q_scale = LOG2E / sqrtf((float)DH);
-    g.q = ws.q;
-    g.k = ws.k;
-    g.v = ws.v;
-    hipLaunchKernelGGL(gemm_k384_kernel<EPI_QKV>, dim3(Tpad / 256), dim3(512), 0, st, g);
-    if ((rc = sskd::check_launch("gemm_k384_kernel<QKV>")) != SSKD_OK) return rc;
-
-    AttnParams a{};
-    a.q = reinterpret_cast<const bf16x8*>(ws.q);
-    a.k = reinterpret_cast<const bf16x8*>(ws.k);
-    a.v = reinterpret_cast<const bf16x8*>(ws.v);
-    a.mask = d_mask;
-    a.S = S;
-    a.nkt = nkt;
-    a.ctx = ws.ctx;
-    const size_t att_lds_bytes = (size_t)nkt * (2 * 128 * sizeof(bf16x8) + 32 * sizeof(float));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)att_lds_bytes);
-    hipLaunchKernelGGL(attention_kernel, dim3(B * NH), dim3(512), att_lds_bytes, st, a);
-    if ((rc = sskd::check_launch("attention_kernel")) != SSKD_OK) return rc;
+    QkvAttnParams qa{};
+    qa.x = reinterpret_cast<const bf16x8*>(x);
+    qa.wqkv = static_cast<const bf16x8*>(lw.wqkv);
+    qa.bqkv = lw.bqkv;
+    qa.mask = d_mask;
+    qa.B = B;
+    qa.S = S;
+    qa.nkt = nkt;
+    qa.q_scale = LOG2E / sqrtf((float)DH);
+    qa.ctx = ws.ctx;
+    const size_t qa_lds_bytes = 3 * WTILE_VEC * sizeof(bf16x8) +
+                                (size_t)nkt * (2 * 128 * sizeof(bf16x8) + 32 * sizeof(float)) + 96 * sizeof(float);
+    auto qa_kernel = nkt > 8 ? qkv_attention_kernel<true> : qkv_attention_kernel<false>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(qa_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)qa_lds_bytes);
+    // all 12 heads per workgroup once there are enough batch rows to fill the chip; fewer heads
+    // per workgroup (more workgroups) for small batches
+    qa.hpw = B >= 256 ? 12 : (B >= 64 ? 4 : 1);
+    hipLaunchKernelGGL(qa_kernel, dim3(B * (NH / qa.hpw)), dim3(512), qa_lds_bytes, st, qa);
+    if ((rc = sskd::check_launch("qkv_attention_kernel")) != SSKD_OK) return rc;
 
     GemmN384Params o{};
     o.x = reinterpret_cast<const bf16x8*>(ws.ctx);
