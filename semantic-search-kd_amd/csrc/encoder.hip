@@ -28,6 +28,8 @@
 //   fused_mlp_ln_kernel     X2 = LN(X1 + gelu(X1 W1^T + b1) W2^T + b2)   (hidden 1536 stays on chip)
 #include "common.h"
 
+#include <type_traits>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -646,22 +648,44 @@ struct QkvAttnParams {
 //                  order, the order P^T's accumulators have) - no transpose anywhere.
 // K and V fragments go to LDS (every wave needs every key), Q stays in registers.
 // Phase 2: flash-style attention per query tile, online softmax lane-local (query on the lane).
+#ifdef SSKD_PROBE
+__device__ unsigned long long g_probe_qa[16][8];
+#define SSKD_QA_STAMP(hi, slot)                                                            \
+  do {                                                                                     \
+    if (blockIdx.x == 0 && wave == 0 && (hi) < 16) {                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                   \
+      unsigned long long t_ = __builtin_amdgcn_s_memtime();                                \
+      __builtin_amdgcn_s_waitcnt(0xC07F);                                                  \
+      if (lane == 0) g_probe_qa[hi][slot] = t_;                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                   \
+    }                                                                                      \
+  } while (0)
+#else
+#define SSKD_QA_STAMP(hi, slot) do {} while (0)
+#endif
+
 // TWO_TILES = sequences longer than 256 tokens: every wave owns two query tiles and re-reads their
 // activations per head (192 resident registers would not fit); otherwise one tile, read once.
+//
+// Software pipeline over heads with a role stagger: in step k every wave runs the projection of
+// head k (MFMA-bound) and the attention of head k-1 (VALU-bound: exp / max / sum), waves 0-3 in
+// that order, waves 4-7 in the opposite order.  Wave w and w + 4 share a SIMD, so each SIMD
+// always has one wave on the matrix pipe and one on the vector pipe.  K / V fragments are
+// double-buffered in LDS (head k is written while head k-1 is read).
 template <bool TWO_TILES>
 __global__ __launch_bounds__(512) void qkv_attention_kernel(QkvAttnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char qa_lds[];
-  // [3 weight tiles: 72 KiB][K frags nkt*2 KiB][V frags nkt*2 KiB][mask bias nkt*32 f32][bias 96 f32]
+  // [3 weight tiles: 72 KiB][2 x (K frags nkt*2 KiB, V frags nkt*2 KiB)][mask bias nkt*32 f32][bias 2 x 96 f32]
   bf16x8* const wlds = reinterpret_cast<bf16x8*>(qa_lds);
-  bf16x8* const klds = wlds + 3 * WTILE_VEC;
-  bf16x8* const vlds = klds + p.nkt * 128;
-  float* const mbias = reinterpret_cast<float*>(vlds + p.nkt * 128);
+  bf16x8* const kvlds = wlds + 3 * WTILE_VEC;  // buffer i: K at i * nkt * 256, V at + nkt * 128
+  float* const mbias = reinterpret_cast<float*>(kvlds + (TWO_TILES ? 1 : 2) * p.nkt * 256);
   float* const bias_lds = mbias + p.nkt * 32;
   __shared__ int s_kmax;
   __shared__ int s_partial[ATT_MAX_S / 32];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool late = wave >= 4;
   const int r = lane & 31, h = lane >> 5;
   // One workgroup = one batch row x `hpw` consecutive heads (hpw = 12 when there are enough rows
   // to fill the chip: the row's activations are then read once and stay in registers).
@@ -703,90 +727,126 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(QkvAttnParams p) {
   };
   load_weights(head0);
 
-  for (int hi = 0; hi < p.hpw; ++hi) {
-    const int head = head0 + hi;
-    __syncthreads();  // previous head: every wave is done with the weights and with K / V
-#pragma unroll
-    for (int i = 0; i < 9; ++i) wlds[tid + 512 * i] = wstage[i];
-    if (tid < 96) bias_lds[tid] = p.bqkv[(tid >> 5) * H + head * DH + (tid & 31)];
-    __syncthreads();
-    if (hi + 1 < p.hpw) load_weights(head + 1);
+  constexpr int NU = TWO_TILES ? 2 : 1;
+  bf16x8 qf_new[NU][2], qf_old[NU][2];  // Q^T fragments of head k / head k-1
 
-    // ---- phase 1: projection of this wave's token tiles ------------------------------------
-    bf16x8 qf[2][2];  // Q^T fragments of up to two query tiles (S <= 512)
-    auto project = [&](const bf16x8 (&x)[KSTEPS], int u, int tq) {
-      f32x16 aq = tile_mfma<KSTEPS, 4>(wlds + lane, x, zero16());
-      f32x16 ak = tile_mfma<KSTEPS, 4>(wlds + WTILE_VEC + lane, x, zero16());
-      // V with the operands swapped: A = activations (row = token), B = weights (col = dim)
-      f32x16 av = zero16();
-      {
-        const bf16x8* wv = wlds + 2 * WTILE_VEC + lane;
+  // ---- projection of one token tile of head (step k): Q^T -> registers, K / V -> LDS buffer k & 1 ----
+  auto project = [&](const bf16x8 (&x)[KSTEPS], int u, int tq, int buf) {
+    // three independent accumulator chains per k-step (Q^T, K^T and - operands swapped: A =
+    // activations, B = weights - V), weight fragments read PF k-steps ahead through a ring
+    f32x16 aq = zero16(), ak = zero16(), av = zero16();
+    {
+      const bf16x8* wq = wlds + lane;
+      const bf16x8* wk = wlds + WTILE_VEC + lane;
+      const bf16x8* wv = wlds + 2 * WTILE_VEC + lane;
+      constexpr int PF = 3, RING = PF + 1;
+      bf16x8 fq[RING], fk[RING], fv[RING];
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s)
-          av = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[s], wv[s * 64], av, 0, 0, 0);
+      for (int i = 0; i < PF; ++i) {
+        fq[i] = wq[i * 64];
+        fk[i] = wk[i * 64];
+        fv[i] = wv[i * 64];
       }
-      // Q^T / K^T: lane = token, acc[4g + e] = dim 8g + 4h + e.  V: lane = dim, acc = keys.
-      bf16x8 kf[2], vf[2];
-      const float bv = bias_lds[64 + r];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 bq = *reinterpret_cast<const f32x4*>(&bias_lds[8 * g + 4 * h]);
-        const f32x4 bk = *reinterpret_cast<const f32x4*>(&bias_lds[32 + 8 * g + 4 * h]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int i = 4 * g + e;
-          qf[u][i >> 3][i & 7] = (__bf16)((aq[i] + bq[e]) * p.q_scale);
-          kf[i >> 3][i & 7] = (__bf16)(ak[i] + bk[e]);
-          vf[i >> 3][i & 7] = (__bf16)(av[i] + bv);
+      for (int s = 0; s < KSTEPS; ++s) {
+        if (s + PF < KSTEPS) {
+          fq[(s + PF) % RING] = wq[(s + PF) * 64];
+          fk[(s + PF) % RING] = wk[(s + PF) * 64];
+          fv[(s + PF) % RING] = wv[(s + PF) * 64];
         }
+        aq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[s % RING], x[s], aq, 0, 0, 0);
+        ak = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk[s % RING], x[s], ak, 0, 0, 0);
+        av = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[s], fv[s % RING], av, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      klds[(tq * 2 + 0) * 64 + lane] = kf[0];
-      klds[(tq * 2 + 1) * 64 + lane] = kf[1];
-      vlds[(tq * 2 + 0) * 64 + lane] = vf[0];
-      vlds[(tq * 2 + 1) * 64 + lane] = vf[1];
-    };
+    }
+    // Q^T / K^T: lane = token, acc[4g + e] = dim 8g + 4h + e.  V: lane = dim, acc = keys.
+    const float* bl = bias_lds + 96 * buf;
+    bf16x8 kf[2], vf[2];
+    const float bv = bl[64 + r];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 bq = *reinterpret_cast<const f32x4*>(&bl[8 * g + 4 * h]);
+      const f32x4 bk = *reinterpret_cast<const f32x4*>(&bl[32 + 8 * g + 4 * h]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * g + e;
+        qf_new[u][i >> 3][i & 7] = (__bf16)((aq[i] + bq[e]) * p.q_scale);
+        kf[i >> 3][i & 7] = (__bf16)(ak[i] + bk[e]);
+        vf[i >> 3][i & 7] = (__bf16)(av[i] + bv);
+      }
+    }
+    bf16x8* kl = kvlds + buf * nkt * 256;
+    bf16x8* vl = kl + nkt * 128;
+    kl[(tq * 2 + 0) * 64 + lane] = kf[0];
+    kl[(tq * 2 + 1) * 64 + lane] = kf[1];
+    vl[(tq * 2 + 0) * 64 + lane] = vf[0];
+    vl[(tq * 2 + 1) * 64 + lane] = vf[1];
+  };
+  auto project_all = [&](int buf) {
     if (!TWO_TILES) {
-      if (wave < nkt) project(x0, 0, wave);
+      if (wave < nkt) project(x0, 0, wave, buf);
     } else {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < NU; ++u) {
         const int tq = wave + 8 * u;
         if (tq < nkt) {
           const bf16x8* xs = p.x + frag_base((int64_t)b * nkt + tq, 0, KSTEPS) + lane;
 #pragma unroll
           for (int s = 0; s < KSTEPS; ++s) x0[s] = xs[s * 64];
-          project(x0, u, tq);
+          project(x0, u, tq, buf);
         }
       }
     }
-    __syncthreads();
-    const int kmax = s_kmax;
+  };
 
-    // ---- phase 2: attention -------------------------------------------------------------------
+  // ---- attention of this wave's query tiles for `head`, K / V from LDS buffer `buf` ------------
+  auto attend = [&](int head, int buf, int kmax) {
+    const bf16x8* kl = kvlds + buf * nkt * 256 + lane;
+    const bf16x8* vl = kl + nkt * 128;
 #pragma unroll
-    for (int u = 0; u < (TWO_TILES ? 2 : 1); ++u) {
+    for (int u = 0; u < NU; ++u) {
       const int qt = wave + 8 * u;
       if (qt >= nkt) break;
-      const bf16x8 qf0 = qf[u][0], qf1 = qf[u][1];
+      const bf16x8 qf0 = qf_old[u][0], qf1 = qf_old[u][1];
       f32x16 o = zero16();
       float m = MASK_NEG, l = 0.f;
-      for (int kt = 0; kt < kmax; ++kt) {
-        f32x16 sc = zero16();
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(klds[(kt * 2 + 0) * 64 + lane], qf0, sc, 0, 0, 0);
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(klds[(kt * 2 + 1) * 64 + lane], qf1, sc, 0, 0, 0);
-        if (s_partial[kt]) {
+      // NT key tiles per iteration: their score MFMAs are independent, and one max / rescale
+      // decision covers all of them - the per-tile work is a long dependent chain (LDS -> MFMA ->
+      // max -> half-wave exchange -> branch -> exp -> convert -> MFMA), so a wave needs this ILP.
+      // (Explicitly software-pipelining the next tile's score MFMAs instead measured slower.)
+      auto tiles = [&](int kt, auto nt_tag) {
+        constexpr int NT = decltype(nt_tag)::value;
+        f32x16 sc[NT];
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x4 mb = *reinterpret_cast<const f32x4*>(&mbias[kt * 32 + 8 * g + 4 * h]);
+        for (int t = 0; t < NT; ++t) {
+          sc[t] = zero16();
+          sc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl[((kt + t) * 2 + 0) * 64], qf0, sc[t], 0, 0, 0);
+          sc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl[((kt + t) * 2 + 1) * 64], qf1, sc[t], 0, 0, 0);
+        }
+        // sc[t][4g + e] = score(key 32(kt + t) + 8g + 4h + e, query = lane), in log2 units
 #pragma unroll
-            for (int e = 0; e < 4; ++e) sc[4 * g + e] += mb[e];
+        for (int t = 0; t < NT; ++t) {
+          if (s_partial[kt + t]) {  // only tiles with masked / padding keys pay for the bias
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x4 mb = *reinterpret_cast<const f32x4*>(&mbias[(kt + t) * 32 + 8 * g + 4 * h]);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) sc[t][4 * g + e] += mb[e];
+            }
           }
         }
-        float mt = sc[0];
+        float mt = fmaxf(fmaxf(sc[0][0], sc[0][1]), sc[0][2]);
 #pragma unroll
-        for (int i = 1; i < 16; ++i) mt = fmaxf(mt, sc[i]);
+        for (int i = 3; i < 15; i += 2) mt = fmaxf(fmaxf(mt, sc[0][i]), sc[0][i + 1]);
+        mt = fmaxf(mt, sc[0][15]);
+#pragma unroll
+        for (int t = 1; t < NT; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; i += 2) mt = fmaxf(fmaxf(mt, sc[t][i]), sc[t][i + 1]);
         mt = pair_max(mt);
         if (__any(mt > m)) {
+          // the running maximum moves (rare after the first tiles): rescale what is accumulated
           const float m_new = fmaxf(m, mt);
           const float alpha = __builtin_amdgcn_exp2f(m - m_new);
           l *= alpha;
@@ -795,17 +855,26 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(QkvAttnParams p) {
           m = m_new;
         }
         float ps = 0.f;
-        bf16x8 pf[2];
+        bf16x8 pf[NT][2];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const float e = __builtin_amdgcn_exp2f(sc[i] - m);
-          ps += e;
-          pf[i >> 3][i & 7] = (__bf16)e;
-        }
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float e = __builtin_amdgcn_exp2f(sc[t][i] - m);
+            ps += e;
+            pf[t][i >> 3][i & 7] = (__bf16)e;
+          }
         l += ps;
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vlds[(kt * 2 + 0) * 64 + lane], pf[0], o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vlds[(kt * 2 + 1) * 64 + lane], pf[1], o, 0, 0, 0);
-      }
+        // O^T[dim, query] += V^T[dim, key] P^T[key, query]; P^T is the accumulator as B operand
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl[((kt + t) * 2 + 0) * 64], pf[t][0], o, 0, 0, 0);
+          o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl[((kt + t) * 2 + 1) * 64], pf[t][1], o, 0, 0, 0);
+        }
+      };
+      int kt = 0;
+      for (; kt + 2 <= kmax; kt += 2) tiles(kt, std::integral_constant<int, 2>{});
+      if (kt < kmax) tiles(kt, std::integral_constant<int, 1>{});
       l = pair_sum(l);
       const float inv = l > 0.f ? 1.0f / l : 0.f;
       f32x4 v[4];
@@ -814,6 +883,53 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(QkvAttnParams p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[g][e] = o[4 * g + e] * inv;
       store_tile_frag(p.ctx + frag_base((int64_t)b * nkt + qt, 2 * head, KSTEPS) * 8, v, lane);
+    }
+  };
+
+  for (int k = 0; k <= p.hpw; ++k) {
+    const bool has_p1 = k < p.hpw, has_p2 = k >= 1;
+    SSKD_QA_STAMP(k, 0);
+    __syncthreads();  // step k-1 complete: weights free, K / V of head k-1 complete
+    SSKD_QA_STAMP(k, 1);
+    if (has_p1) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) wlds[tid + 512 * i] = wstage[i];
+      if (tid < 96) bias_lds[96 * (k & 1) + tid] = p.bqkv[(tid >> 5) * H + (head0 + k) * DH + (tid & 31)];
+    }
+    SSKD_QA_STAMP(k, 2);
+    __syncthreads();
+    SSKD_QA_STAMP(k, 3);
+    if (k + 1 < p.hpw) load_weights(head0 + k + 1);
+    const int kmax = s_kmax;
+    SSKD_QA_STAMP(k, 4);
+    if (TWO_TILES) {
+      // S > 256: double-buffered K / V would not fit LDS -> plain schedule, one buffer
+      if (has_p1) {
+        project_all(0);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          qf_old[u][0] = qf_new[u][0];
+          qf_old[u][1] = qf_new[u][1];
+        }
+        attend(head0 + k, 0, kmax);
+      }
+      continue;
+    }
+    if (!late) {
+      if (has_p1) project_all(k & 1);
+      SSKD_QA_STAMP(k, 5);
+      if (has_p2) attend(head0 + k - 1, (k - 1) & 1, kmax);
+    } else {
+      if (has_p2) attend(head0 + k - 1, (k - 1) & 1, kmax);
+      SSKD_QA_STAMP(k, 5);
+      if (has_p1) project_all(k & 1);
+    }
+    SSKD_QA_STAMP(k, 6);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      qf_old[u][0] = qf_new[u][0];
+      qf_old[u][1] = qf_new[u][1];
     }
   }
 }
@@ -977,7 +1093,7 @@ int run_layers(const sskd_encoder_config* cfg, const sskd_encoder_weights* w, co
     qa.q_scale = LOG2E / sqrtf((float)DH);
     qa.ctx = ws.ctx;
     const size_t qa_lds_bytes = 3 * WTILE_VEC * sizeof(bf16x8) +
-                                (size_t)nkt * (2 * 128 * sizeof(bf16x8) + 32 * sizeof(float)) + 96 * sizeof(float);
+                                (size_t)nkt * ((nkt > 8 ? 2 : 4) * 128 * sizeof(bf16x8) + 32 * sizeof(float)) + 2 * 96 * sizeof(float);
     auto qa_kernel = nkt > 8 ? qkv_attention_kernel<true> : qkv_attention_kernel<false>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(qa_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)qa_lds_bytes);
