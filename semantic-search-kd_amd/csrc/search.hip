@@ -122,6 +122,7 @@ struct ScanParams {
   const float* ub_scores;  // chained pass: exclusive upper bound per query
   const int* ub_ids;
   int* tau;                // shared per-query threshold (monotone int image of a float), see below
+  int* gpool;              // [nq][K] global candidate pool whose minimum feeds tau
   int64_t n_rows;
   int n_tiles;
   int nq;
@@ -147,7 +148,44 @@ __device__ inline int float_to_ordered(float x) {
   return b >= 0 ? b : b ^ 0x7FFFFFFF;
 }
 __device__ inline float ordered_to_float(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF); }
-constexpr int TAU_REFRESH_TILES = 8;  // re-read the shared bound every this many tiles
+constexpr int TAU_REFRESH_TILES = 8;  // exchange bounds with global memory every this many tiles
+
+// Workgroup pool.  A single list's K-th entry is a weak bound (a list sees 1/128 of a query's
+// rows).  Every row a lane accepts is therefore also offered to a per-query pool of K slots in LDS
+// shared by the workgroup's 16 lists: lock-free, "replace the current minimum by compare-and-swap".
+// Slot values only grow and each is the score of a distinct row seen by this workgroup, so the
+// minimum over any (even stale) snapshot of a full pool is a valid lower bound on the query's
+// final K-th score; it is cached in `wthr` (one LDS word per query, atomicMax).  What a workgroup
+// pool accepts after its first tile is forwarded to a second pool of the same kind in global
+// memory (device-scope atomics; its minimum is `tau`), which therefore converges to the K-th best
+// score over everything all workgroups have scanned.  The first tile is skipped because every
+// workgroup starts with empty pools at the same instant and would only fight over the slots.
+// Images are the monotone integers of float_to_ordered(); INT_MIN = empty.
+template <int K, bool GLOBAL>
+__device__ inline bool pool_offer(int* __restrict__ slots, int* __restrict__ thr, int xi) {
+#pragma unroll 1
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    int v[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+      v[i] = GLOBAL ? __hip_atomic_load(&slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : slots[i];
+    int mn = v[0], mi = 0;
+#pragma unroll
+    for (int i = 1; i < K; ++i)
+      if (v[i] < mn) { mn = v[i]; mi = i; }
+    if (xi <= mn) return false;  // not among the K best seen so far
+    if (atomicCAS(&slots[mi], mn, xi) == mn) {
+      // minimum of our snapshot with the replaced slot
+      int nm = xi;
+#pragma unroll
+      for (int i = 0; i < K; ++i)
+        if (i != mi && v[i] < nm) nm = v[i];
+      if (nm != (int)0x80000000) atomicMax(thr, nm);
+      return true;
+    }
+  }
+  return false;  // lost the race four times: the pool just stays a little looser
+}
 
 #ifdef SSKD_PROBE
 // diagnostic build only (tools/scan_probe.hip): [0] tiles, [1] slow-path entries, [2] per-register
@@ -233,16 +271,24 @@ __global__ __launch_bounds__(WAVES * 64) void scan_topk_kernel(ScanParams p) {
   __syncthreads();
   const float4* qlane = qs + h * 32 + j;
 
+  // workgroup pool: [QB * 32 queries][K slots] + one cached minimum per query, behind the query block
+  int* const pool = reinterpret_cast<int*>(qs + QB * 32 * CHUNKS);
+  int* const wthr = pool + QB * 32 * K;
+  for (int i = tid; i < QB * 32 * (K + 1); i += WAVES * 64) pool[i] = (int)0x80000000;
+  __syncthreads();
+
   LaneList<K> list[QB];
   float ub_s[QB];
   int ub_i[QB];
-  float gthr[QB];  // last seen value of the shared threshold
+  float gthr[QB];  // best known lower bound on the query's final K-th score
   int* tau_q[QB];
+  bool real[QB];  // padding queries (>= nq) share the last query's words and must never write them
 #pragma unroll
   for (int qq = 0; qq < QB; ++qq) {
     gthr[qq] = -INFINITY;
     const int qg = q0 + qq * 32 + j;
-    tau_q[qq] = p.tau + (qg < p.nq ? qg : p.nq - 1);
+    real[qq] = qg < p.nq;
+    tau_q[qq] = p.tau + (real[qq] ? qg : p.nq - 1);
     list[qq].clear();
     ub_s[qq] = INFINITY;
     ub_i[qq] = -1;
@@ -264,11 +310,16 @@ __global__ __launch_bounds__(WAVES * 64) void scan_topk_kernel(ScanParams p) {
   int tiles_done = 0;
   for (; t < t_end; t += WAVES, ++tiles_done) {
     const float* tile = lane_base + (int64_t)t * TILE_FLOATS;
-    if (tiles_done % TAU_REFRESH_TILES == 0) {
-      // fresh read of the shared bound (an atomic executes at the memory side)
+    // the workgroup's bound every tile (one LDS word), the global one every few tiles: an atomic
+    // executes at the memory side, so it both publishes ours and returns a fresh value
+    const bool exchange = tiles_done < TAU_REFRESH_TILES ? (tiles_done & (tiles_done - 1)) == 0
+                                                         : tiles_done % TAU_REFRESH_TILES == 0;
 #pragma unroll
-      for (int qq = 0; qq < QB; ++qq)
-        gthr[qq] = fmaxf(gthr[qq], ordered_to_float(atomicMax(tau_q[qq], (int)0x80000000)));
+    for (int qq = 0; qq < QB; ++qq) {
+      const int w = wthr[qq * 32 + j];
+      gthr[qq] = fmaxf(gthr[qq], ordered_to_float(w));
+      if (exchange && real[qq])
+        gthr[qq] = fmaxf(gthr[qq], ordered_to_float(atomicMax(tau_q[qq], w)));
     }
     f32x16 acc[QB];
 #pragma unroll
@@ -318,15 +369,24 @@ __global__ __launch_bounds__(WAVES * 64) void scan_topk_kernel(ScanParams p) {
             SSKD_COUNT(3, __popcll(__ballot(take)));
             if (take) {
               list[qq].insert(x, xid);
+              // (a wave's first tile fills empty lists: nearly every row is taken, so only the
+              // best of them is offered afterwards instead of all sixteen)
+              if (tiles_done > 0) {
+                const int xi = float_to_ordered(x);
+                if (pool_offer<K, false>(pool + (qq * 32 + j) * K, wthr + qq * 32 + j, xi) && real[qq])
+                  pool_offer<K, true>(p.gpool + (int64_t)(q0 + qq * 32 + j) * K, tau_q[qq], xi);
+              }
               grew = true;
             }
           }
         }
-        // publish this list's K-th entry (once it exists) and pick up everybody else's
-        if (grew && list[qq].s[K - 1] > -INFINITY) {
+        // pick up what the pool learned (our own list's K-th entry is implied by it)
+        if (grew) {
           SSKD_COUNT(4, __popcll(__ballot(true)));
-          const int old = atomicMax(tau_q[qq], float_to_ordered(list[qq].s[K - 1]));
-          gthr[qq] = fmaxf(gthr[qq], fmaxf(ordered_to_float(old), list[qq].s[K - 1]));
+          if (tiles_done == 0)
+            pool_offer<K, false>(pool + (qq * 32 + j) * K, wthr + qq * 32 + j,
+                                 float_to_ordered(list[qq].s[0]));
+          gthr[qq] = fmaxf(gthr[qq], fmaxf(ordered_to_float(wthr[qq * 32 + j]), list[qq].s[K - 1]));
         }
       }
     }
@@ -535,7 +595,7 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 template <int K, int QB, bool HAS_UB>
 void launch_scan(const Plan& pl, const ScanParams& sp, hipStream_t st) {
   constexpr int WAVES = 8;
-  const size_t lds = (size_t)QB * 32 * CHUNKS * sizeof(float4);
+  const size_t lds = (size_t)QB * 32 * CHUNKS * sizeof(float4) + (size_t)QB * 32 * (K + 1) * sizeof(int);
   auto kern = scan_topk_kernel<K, QB, WAVES, HAS_UB>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -610,7 +670,8 @@ size_t sskd_index_search_workspace_bytes(int64_t n_rows, int nq, int k) {
   if (n_rows < 0 || nq <= 0 || k <= 0) return 0;
   const Plan pl = make_plan(n_rows, nq, k);
   return align256(pl.part_elems * sizeof(float)) + align256(pl.part_elems * sizeof(int)) +
-         align256((size_t)nq * sizeof(float)) + 2 * align256((size_t)nq * sizeof(int));
+         align256((size_t)nq * sizeof(float)) + align256((size_t)nq * sizeof(int)) +
+         align256((size_t)nq * (1 + pl.K) * sizeof(int));
 }
 
 int sskd_index_search_plan(int64_t n_rows, int nq, int k, int* queries_per_block,
@@ -676,6 +737,7 @@ int sskd_index_search_profiled(const float* d_tiled, int64_t n_rows, const float
   sp.ub_scores = ub_scores;
   sp.ub_ids = ub_ids;
   sp.tau = tau;
+  sp.gpool = tau + nq;  // filled together with tau
   sp.n_rows = n_rows;
   sp.n_tiles = pl.n_tiles;
   sp.nq = nq;
@@ -684,8 +746,8 @@ int sskd_index_search_profiled(const float* d_tiled, int64_t n_rows, const float
   sp.lists_per_query = pl.lists_per_query;
 
   for (int pass = 0; pass < pl.passes; ++pass) {
-    hipLaunchKernelGGL(fill_int_kernel, dim3((unsigned)sskd::ceil_div(nq, 256)), dim3(256), 0, st, tau,
-                       nq, (int)0x80000000);
+    hipLaunchKernelGGL(fill_int_kernel, dim3((unsigned)sskd::ceil_div(nq * (1 + pl.K), 256)), dim3(256),
+                       0, st, tau, nq * (1 + pl.K), (int)0x80000000);
     if (pass == 0 && ev_scan_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_scan_begin), st);
     int rc = pass == 0 ? dispatch_scan<false>(pl, sp, st) : dispatch_scan<true>(pl, sp, st);
     if (pass == 0 && ev_scan_end) (void)hipEventRecord(static_cast<hipEvent_t>(ev_scan_end), st);

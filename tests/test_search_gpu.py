@@ -116,6 +116,27 @@ def test_ties_resolve_to_lower_id(gpu, native_lib):
     assert np.array_equal(i[0], np.arange(10))
 
 
+@pytest.mark.parametrize("nq", [1, 33, 65])
+def test_all_negative_scores_with_padded_query_lanes(gpu, native_lib, nq):
+    """Padding queries score 0 on every row; that bound must never leak into a real query."""
+    d = oracle.seeded_unit_rows(1, 384, 21)
+    queries = oracle.l2_normalize_rows(d + 0.3 * oracle.seeded_unit_rows(nq, 384, 22))
+    corpus = oracle.l2_normalize_rows(-d + 0.3 * oracle.seeded_unit_rows(20000, 384, 23))
+    s, _ = _check_exact(native_lib, corpus, queries, 10)
+    assert (s < 0).all()
+    _check_exact(native_lib, corpus[:3000], queries, 40)
+
+
+def test_many_exact_ties_across_workgroups(gpu, native_lib):
+    """Each score occurs 20 times, spread over every slice: the shared pools must keep ties."""
+    base = oracle.seeded_unit_rows(1000, 384, 31)
+    corpus = np.tile(base, (20, 1))
+    queries = oracle.seeded_unit_rows(70, 384, 32)
+    s, i = _check_exact(native_lib, corpus, queries, 10)
+    assert (np.diff(i, axis=1) == 1000).all()  # the ten lowest-id copies of the best row
+    _check_exact(native_lib, corpus, queries[:5], 50)
+
+
 def test_adversarial_ascending_scores(gpu, native_lib):
     """Every row beats all earlier ones (worst case for the running threshold)."""
     q = oracle.seeded_unit_rows(1, 384, 3)
