@@ -34,6 +34,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -396,6 +398,9 @@ struct MlpParams {
 };
 
 constexpr int MLP_CHUNKS = FF / 32;  // 48
+#ifndef SSKD_MLP_PF
+#define SSKD_MLP_PF 6
+#endif
 
 #ifdef SSKD_PROBE
 // diagnostic build only (tools/mlp_probe.hip): s_memtime stamps of workgroup 0, waves 0 and 4
@@ -414,20 +419,39 @@ __device__ unsigned long long g_probe[2][64][4];
 #define SSKD_STAMP(role, it, slot) do {} while (0)
 #endif
 
-// Workgroup = 8 waves = 128 tokens.  Waves 0-3 are PRODUCERS, waves 4-7 CONSUMERS; wave w and
-// w + 4 own the same 32-token tile and (waves of a workgroup are dealt to SIMDs cyclically)
-// share a SIMD, so every SIMD runs one of each:
-//   producer, iteration i : hT = W1[chunk i] X1^T            (24 MFMAs, X1 in 96 registers)
-//                           + bias, GELU, bf16 of chunk i-1  -> 2 KiB B-operand image in LDS
-//   consumer, iteration i : Y^T[12 tiles] += W2[:, chunk i-2] hT[i-2]   (24 MFMAs, 192 accumulators)
-// One barrier per iteration.  The consumer never issues anything but LDS reads and MFMAs, so
-// the matrix pipe keeps running while the producer works through GELU; the hidden activations
-// never touch HBM.  At the end the consumer holds every feature of its tokens: bias + residual +
-// LayerNorm stay inside the lane pair.
+// Workgroup = 8 waves = 128 tokens.  Waves 0-3 are PRODUCERS (hT = W1 X1^T, X1 in 96 registers),
+// waves 4-7 CONSUMERS (Y^T += W2 hT, 192 accumulators); wave w and w + 4 own the same 32-token
+// tile and (waves of a workgroup are dealt to SIMDs cyclically) share a SIMD.
+//
+// The two waves of a SIMD share its matrix pipe and its vector issue port, and an in-order wave
+// cannot slip an MFMA into the gaps of its partner's MFMA stream: with both waves mixing MFMAs
+// and VALU work all the time this kernel measured 64 cycles per MFMA (ablations: removing the
+// producers' MFMAs changed nothing, removing the consumers' halved the time).  So every
+// iteration has two phases, separated by workgroup barriers, in which exactly one wave of each
+// SIMD runs a dense MFMA burst while its partner does the vector and memory work:
+//
+//   phase 1   producer: 24 MFMAs  hT = W1[chunk i] X1^T   (weight loads for later chunks in flight)
+//             consumer: GELU of its half of chunk i-1 -> B fragments in registers; first W2
+//                       fragments of its burst
+//   phase 2   consumer: 24 MFMAs  Y^T[12 tiles] += W2[:, chunk i-1] hT[i-1]
+//             producer: bias + GELU of its half of chunk i -> LDS; weight loads -> LDS; first W1
+//                       fragments of chunk i+1
+//
+// GELU is ~14 VALU instructions per element; it is split between the two waves so that both
+// vector phases are short.  The consumer's half crosses the LDS as fp32 (bias already added), so
+// no value is rounded twice.  The hidden activations never touch HBM.  At the end the consumer holds every
+// feature of its tokens: bias + residual + LayerNorm stay inside the lane pair.
+//
+// Hand-over layout.  h^T accumulator element 4g + e of producer lane (r, hp) is hidden unit
+// 8g + 4hp + e of token r = element j = 4hp + e of the B-operand fragment s2 = g >> 1 of consumer
+// lane r + 32 (g & 1).  The producer finishes e = 0, 1 (dword hp of `hdone`, bf16 pair j = 4hp,
+// 4hp + 1) and passes e = 2, 3 on (floats 2hp, 2hp + 1 of `hraw`, j = 4hp + 2, 4hp + 3): the
+// consumer's fragment is { done.x, pk(raw0, raw1), done.y, pk(raw2, raw3) } - whole dwords only.
 __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
-  __shared__ bf16x8 w1buf[2][WTILE_VEC];          // 2 x 24 KiB
-  __shared__ bf16x8 w2buf[2][WTILE_VEC];          // 2 x 24 KiB
-  __shared__ bf16x8 hbuf[4][2][128];              // [token tile][slot][2 k-steps x 64 lanes]
+  __shared__ bf16x8 w1buf[2][WTILE_VEC];          // 2 x 24 KiB (chunk i in i % 2)
+  __shared__ bf16x8 w2buf[2][WTILE_VEC];          // 2 x 24 KiB (chunk i in i % 2)
+  __shared__ u32x2 hdone[4][2][64];               // [token tile][fragment][consumer lane]
+  __shared__ f32x4 hraw[4][2][64];
   __shared__ __attribute__((aligned(16))) float b1_lds[FF];
   __shared__ __attribute__((aligned(16))) float par_lds[3][H];  // b2, gamma, beta
   const int tid = threadIdx.x;
@@ -444,10 +468,12 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
     par_lds[1][i] = p.gamma[i];
     par_lds[2][i] = p.beta[i];
   }
-  // W1 chunk 0 for iteration 0
+  // W1 chunk 0
   for (int i = tid; i < WTILE_VEC; i += 512) w1buf[0][i] = p.w1[i];
   __syncthreads();
 
+  // iterations 0 .. MLP_CHUNKS: the producer's burst is real for it < MLP_CHUNKS, the consumer's
+  // for it >= 1; edge phases work on stale data whose results nobody reads (branch-free).
   if (producer) {
     bf16x8 x[KSTEPS];
     {
@@ -455,129 +481,150 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
 #pragma unroll
       for (int s = 0; s < KSTEPS; ++s) x[s] = xs[s * 64];
     }
-    // Weight staging goes through registers (LDS-DMA was measured slower here: its 1 KiB pieces
-    // cost 100-150 issue cycles each in these in-order waves and their writes stall fragment
-    // reads) and is software-pipelined two iterations deep: the 6 loads of W1 chunk it+2 are
-    // sprinkled between this iteration's MFMAs (a burst of loads right after the barrier keeps
-    // all 8 waves stuck in the CU's 64 B/clk address path while the matrix pipe idles), travel
-    // across the barrier in registers and are written to LDS at the start of iteration it+1,
-    // one full iteration before their first use.  Consumers do the same for W2.
-    f32x16 prev = zero16();
-    bf16x8 stage[6];
+    // ring of PF + 1 registers: the read issued in slot s targets the register consumed in slot
+    // s - 1, never the one the MFMA just issued is still reading (WAR stall)
+    constexpr int PF = SSKD_MLP_PF, RING = PF + 1;
+    bf16x8 a[RING];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) stage[i] = p.w1[WTILE_VEC + tid + 256 * i];  // chunk 1
-    for (int it = 0; it <= MLP_CHUNKS + 1; ++it) {
+    for (int i = 0; i < PF; ++i) a[i] = w1buf[0][lane + i * 64];
+    // Weight staging (all of it on the producers: the consumers have no registers to spare) goes
+    // through registers, one vector per thread at a time (a burst of loads would keep all four
+    // producers stuck in the CU's 64 B/clk address path): st1 holds W1 chunk it+1 and st2 W2 chunk
+    // it, loaded one iteration ago; each is written to LDS and immediately reloaded with the
+    // next chunk, one vector after every second MFMA of the burst.  (Moving the W2 half into the
+    // vector phase just moves its ~500 cycles there: measured slower.  Packed-fp32 GELU measured
+    // slower too: v_pk_* is no bargain on these in-order waves.)  W1 chunk it+1 -> buffer (it+1) & 1 (tenant
+    // it-1, last read in the burst of it-1; first read in this iteration's phase 2); W2 chunk it
+    // -> buffer it & 1 (tenant it-2, read by the consumers' burst of it-1; first read in it+1).
+    bf16x8 st1[6], st2[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      st1[i] = p.w1[WTILE_VEC + tid + 256 * i];
+      st2[i] = p.w2c[tid + 256 * i];
+    }
+    for (int it = 0; it <= MLP_CHUNKS; ++it) {
       SSKD_STAMP(0, it, 0);
-      // stage[i] holds W1 chunk it+1 (loaded during iteration it-1): it is written to LDS and
-      // immediately reloaded with chunk it+2, one vector every fourth MFMA slot, so neither the
-      // LDS-fill nor the load issue ever forms a burst.  (Edge iterations write a buffer nobody
-      // reads and reload the clamped last chunk: branch-free.)
-      bf16x8* const stage_dst = w1buf[(it + 1) & 1] + tid;
-      const bf16x8* next_src = p.w1 + (int64_t)(it + 2 < MLP_CHUNKS ? it + 2 : MLP_CHUNKS - 1) * WTILE_VEC + tid;
-      SSKD_STAMP(0, it, 1);
-      // 24 chained MFMAs of chunk `it`, with the bias + GELU + bf16 pack of chunk it-1 woven
-      // in by hand: one element after each of the first 16 MFMAs.  An in-order wave would
-      // otherwise run MFMAs and ~300 VALU instructions back to back; the hard scheduling
-      // fences keep the compiler from regrouping them.  (Edge iterations compute on zeros /
-      // write an unused image: branch-free on purpose, so the body stays one basic block.)
+      // ---- phase 1: MFMA burst ----
       f32x16 acc = zero16();
       {
         const bf16x8* wl = w1buf[it & 1] + lane;
-        const int c = it >= 1 ? it - 1 : 0;
-        __bf16* hb = reinterpret_cast<__bf16*>(&hbuf[tg][c & 1][0]);
+        bf16x8* const d1 = w1buf[(it + 1) & 1] + tid;
+        bf16x8* const d2 = w2buf[it & 1] + tid;
+        const bf16x8* const s1 = p.w1 + (int64_t)(it + 2 < MLP_CHUNKS ? it + 2 : MLP_CHUNKS - 1) * WTILE_VEC + tid;
+        const bf16x8* const s2 = p.w2c + (int64_t)(it + 1 < MLP_CHUNKS ? it + 1 : MLP_CHUNKS - 1) * WTILE_VEC + tid;
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(3);  // the burst wins issue arbitration; the partner's VALU fills the gaps
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s % RING], x[s], acc, 0, 0, 0);
+          if (s + PF < KSTEPS) a[(s + PF) % RING] = wl[(s + PF) * 64];
+          if (s % 4 == 1) {
+            d1[256 * (s / 4)] = st1[s / 4];
+            st1[s / 4] = s1[256 * (s / 4)];
+          }
+          if (s % 4 == 3) {
+            d2[256 * (s / 4)] = st2[s / 4];
+            st2[s / 4] = s2[256 * (s / 4)];
+          }
+          __builtin_amdgcn_sched_barrier(0);  // keep the reads PF slots ahead of their use
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      SSKD_STAMP(0, it, 1);
+      __syncthreads();
+      SSKD_STAMP(0, it, 2);
+      // ---- phase 2: vector work while the consumer multiplies ----
+      {
+        const int c = it < MLP_CHUNKS ? it : MLP_CHUNKS - 1;
         f32x4 bias[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           bias[g] = *reinterpret_cast<const f32x4*>(&b1_lds[c * 32 + 8 * g + 4 * h]);
-        // ring of PF + 1 registers: the read issued in slot s targets the register consumed in
-        // slot s - 1, never the one the MFMA just issued is still reading (WAR stall)
-        constexpr int PF = 6;  // fragments in flight
-        constexpr int RING = PF + 1;
-        bf16x8 a[RING];
+        // first fragments of the next burst (chunk it+1 was written during this iteration's burst)
+        const bf16x8* wn = w1buf[(it + 1) & 1] + lane;
 #pragma unroll
-#if defined(SSKD_PROBE) && SSKD_PROBE_NO_PROD_LDS
-#define SSKD_PIDX(i) 0
-#else
-#define SSKD_PIDX(i) (i)
-#endif
-        for (int i = 0; i < PF; ++i) a[i] = wl[SSKD_PIDX(i) * 64];
-        f32x4 v[4];
+        for (int i = 0; i < PF; ++i) a[i] = wn[i * 64];
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s % RING], x[s], acc, 0, 0, 0);
-          if (s + PF < KSTEPS) a[(s + PF) % RING] = wl[SSKD_PIDX(s + PF) * 64];
-          if (s % 4 == 1) {
-            stage_dst[256 * (s / 4)] = stage[s / 4];
-            stage[s / 4] = next_src[256 * (s / 4)];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          if (s < 16) {
-            const int g = s >> 2, e = s & 3;
-            v[g][e] = gelu_erf(prev[s] + bias[g][e]);
-            if (e == 3)
-              *reinterpret_cast<bf16x4*>(hb + ((g >> 1) * 64 + r + 32 * (g & 1)) * 8 + 4 * h) =
-                  __builtin_convertvector(v[g], bf16x4);
-          }
-          __builtin_amdgcn_sched_barrier(0);
+        for (int g = 0; g < 4; ++g) {
+          const int dl = r + 32 * (g & 1);
+          f32x2 rw;
+          rw[0] = acc[4 * g + 2] + bias[g][2];
+          rw[1] = acc[4 * g + 3] + bias[g][3];
+          reinterpret_cast<f32x2*>(&hraw[tg][g >> 1][dl])[h] = rw;
+          f32x2 pre;
+          pre[0] = acc[4 * g + 0] + bias[g][0];
+          pre[1] = acc[4 * g + 1] + bias[g][1];
+          bf16x2 pk;
+          pk[0] = (__bf16)gelu_erf(pre[0]);
+          pk[1] = (__bf16)gelu_erf(pre[1]);
+          reinterpret_cast<bf16x2*>(&hdone[tg][g >> 1][dl])[h] = pk;
         }
       }
-      prev = acc;
-      SSKD_STAMP(0, it, 2);
-      __syncthreads();
       SSKD_STAMP(0, it, 3);
+      __syncthreads();
     }
   } else {
     f32x16 y[12];
 #pragma unroll
     for (int nt = 0; nt < 12; ++nt) y[nt] = zero16();
-    const int ctid = tid - 256;
-    bf16x8 stage[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) stage[i] = zero_bf8();
-    for (int it = 0; it <= MLP_CHUNKS + 1; ++it) {
+    constexpr int CR = 5;  // fragment ring of the burst, in output tiles (reads run CR - 1 tiles ahead)
+    for (int it = 0; it <= MLP_CHUNKS; ++it) {
       SSKD_STAMP(1, it, 0);
-      // stage[i] holds W2 chunk it-1 (loaded during iteration it-1): written to w2buf[(it-1)&1]
-      // (first used in iteration it+1) and reloaded with chunk `it`, one vector after every second
-      // output tile.  In iteration 0 the write lands in the buffer of chunk 1, before anything
-      // real is stored there.
-      bf16x8* const stage_dst = w2buf[(it + 1) & 1] + ctid;
-      const bf16x8* next_src = p.w2c + (int64_t)(it < MLP_CHUNKS ? it : MLP_CHUNKS - 1) * WTILE_VEC + ctid;
-      SSKD_STAMP(1, it, 1);
-      if (it >= 2) {
-        const int c = it - 2;
-        const bf16x8* wl = w2buf[c & 1] + lane;
-        const bf16x8 hf0 = hbuf[tg][c & 1][lane], hf1 = hbuf[tg][c & 1][64 + lane];
-        // 12 output tiles x 2 k-steps; fragments of tile nt+2 are read while tile nt multiplies;
-        // one staging load of W2 chunk `it` after every second tile
-        bf16x8 a[3][2];
-        a[0][0] = wl[0];
-        a[0][1] = wl[64];
-        a[1][0] = wl[128];
-        a[1][1] = wl[192];
+      // ---- phase 1: vector work while the producer multiplies ----
+      bf16x8 hf0, hf1;
+      bf16x8 a[CR][2];
+      const bf16x8* wl = w2buf[(it + 1) & 1] + lane;  // chunk it-1, staged in phase 2 of it-1
+      {
+        u32x4 hn[2];
 #pragma unroll
-        for (int nt = 0; nt < 12; ++nt) {
-          if (nt + 2 < 12) {
-            a[(nt + 2) % 3][0] = wl[((nt + 2) * 2) * 64];
-            a[(nt + 2) % 3][1] = wl[((nt + 2) * 2 + 1) * 64];
-          }
-          y[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt % 3][0], hf0, y[nt], 0, 0, 0);
-          y[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt % 3][1], hf1, y[nt], 0, 0, 0);
-          if (nt % 2 == 1) {
-            stage_dst[256 * (nt / 2)] = stage[nt / 2];
-            stage[nt / 2] = next_src[256 * (nt / 2)];
-          }
-          __builtin_amdgcn_sched_barrier(0);
+        for (int f = 0; f < 2; ++f) {
+          const u32x2 dn = hdone[tg][f][lane];
+          const f32x4 rw = hraw[tg][f][lane];
+          bf16x2 lo, hi;
+          lo[0] = (__bf16)gelu_erf(rw[0]);
+          lo[1] = (__bf16)gelu_erf(rw[1]);
+          hi[0] = (__bf16)gelu_erf(rw[2]);
+          hi[1] = (__bf16)gelu_erf(rw[3]);
+          hn[f][0] = dn[0];
+          hn[f][1] = __builtin_bit_cast(unsigned int, lo);
+          hn[f][2] = dn[1];
+          hn[f][3] = __builtin_bit_cast(unsigned int, hi);
         }
-      } else {
+        // (the fragments are only used inside the conditional burst below: without this the
+        // compiler sinks the whole GELU computation past the barrier, into the burst phase)
+        asm volatile("" : "+v"(hn[0]), "+v"(hn[1]));
+        hf0 = __builtin_bit_cast(bf16x8, hn[0]);
+        hf1 = __builtin_bit_cast(bf16x8, hn[1]);
+        // first fragments of the burst
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          stage_dst[256 * i] = stage[i];
-          stage[i] = next_src[256 * i];
+        for (int i = 0; i < CR - 1; ++i) {
+          a[i][0] = wl[(2 * i) * 64];
+          a[i][1] = wl[(2 * i + 1) * 64];
         }
       }
-      SSKD_STAMP(1, it, 2);
+      SSKD_STAMP(1, it, 1);
       __syncthreads();
+      SSKD_STAMP(1, it, 2);
+      // ---- phase 2: MFMA burst, 12 output tiles x 2 k-steps ----
+      if (it >= 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int nt = 0; nt < 12; ++nt) {
+          if (nt + CR - 1 < 12) {
+            a[(nt + CR - 1) % CR][0] = wl[((nt + CR - 1) * 2) * 64];
+            a[(nt + CR - 1) % CR][1] = wl[((nt + CR - 1) * 2 + 1) * 64];
+          }
+          y[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt % CR][0], hf0, y[nt], 0, 0, 0);
+          y[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt % CR][1], hf1, y[nt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       SSKD_STAMP(1, it, 3);
+      __syncthreads();
     }
 
     // epilogue: v = y + b2 + residual; LayerNorm over the token's 384 features (192 in this
