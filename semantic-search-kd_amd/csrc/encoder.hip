@@ -858,35 +858,25 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(QkvAttnParams p) {
       if (qt >= nkt) break;
       const bf16x8 qf0 = qf_old[u][0], qf1 = qf_old[u][1];
       f32x16 o = zero16();
-      // Online softmax without a subtraction per score: the running maximum m enters the score
-      // MFMA as its C operand (a tile holding -m in every register), so the accumulators come out
-      // as s - m and go straight into exp2.  m only moves on the (rare) rescale path, which then
-      // also rewrites the tile.  Until a tile with an unmasked key has been seen m is 0 and that
-      // path is forced (fully masked leading tiles contribute exp2(-1e30) = 0 and change nothing).
-      f32x16 negm = zero16();
-      float l = 0.f;
-      bool seen = false;
+      float m = MASK_NEG, l = 0.f;
       // NT key tiles per iteration: their score MFMAs are independent, and one max / rescale
       // decision covers all of them - the per-tile work is a long dependent chain (LDS -> MFMA ->
       // max -> half-wave exchange -> branch -> exp -> convert -> MFMA), so a wave needs this ILP.
-      // (Explicitly software-pipelining the next tile's score MFMAs instead measured slower.)
-      // K fragments of the tile pair about to be scored: read one iteration ahead (before the PV
-      // MFMAs of the previous pair), so the score MFMAs never wait on the LDS
-      bf16x8 kf[2][2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        kf[t][0] = kl[(t * 2 + 0) * 64];
-        kf[t][1] = kl[(t * 2 + 1) * 64];
-      }
+      // (Explicitly software-pipelining the next tile's score MFMAs instead measured slower.  So
+      // did, on the real workload where the maximum moves often: feeding -m into the score MFMA
+      // as its C operand to drop the subtraction, summing the bf16 weights with v_dot2c, reading
+      // the K fragments one iteration ahead, and a static s_setprio for the late half - the two
+      // waves of a SIMD are latency-bound here and what one gains the other loses.)
       auto tiles = [&](int kt, auto nt_tag) {
         constexpr int NT = decltype(nt_tag)::value;
         f32x16 sc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          sc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t][0], qf0, negm, 0, 0, 0);
-          sc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t][1], qf1, sc[t], 0, 0, 0);
+          sc[t] = zero16();
+          sc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl[((kt + t) * 2 + 0) * 64], qf0, sc[t], 0, 0, 0);
+          sc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl[((kt + t) * 2 + 1) * 64], qf1, sc[t], 0, 0, 0);
         }
-        // sc[t][4g + e] = score(key 32(kt + t) + 8g + 4h + e, query = lane) - m, in log2 units
+        // sc[t][4g + e] = score(key 32(kt + t) + 8g + 4h + e, query = lane), in log2 units
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           if (s_partial[kt + t]) {  // only tiles with masked / padding keys pay for the bias
@@ -898,67 +888,35 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(QkvAttnParams p) {
             }
           }
         }
-        // (independent max chains: a dependent VALU chain runs at latency, not issue, speed)
-        float mx[NT][2];
+        float mt = fmaxf(fmaxf(sc[0][0], sc[0][1]), sc[0][2]);
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int i = 3; i < 15; i += 2) mt = fmaxf(fmaxf(mt, sc[0][i]), sc[0][i + 1]);
+        mt = fmaxf(mt, sc[0][15]);
 #pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            mx[t][c] = fmaxf(fmaxf(sc[t][8 * c], sc[t][8 * c + 1]), sc[t][8 * c + 2]);
-            mx[t][c] = fmaxf(fmaxf(mx[t][c], sc[t][8 * c + 3]), sc[t][8 * c + 4]);
-            mx[t][c] = fmaxf(fmaxf(mx[t][c], sc[t][8 * c + 5]), sc[t][8 * c + 6]);
-            mx[t][c] = fmaxf(mx[t][c], sc[t][8 * c + 7]);
-          }
-        float mt = fmaxf(mx[0][0], mx[0][1]);
+        for (int t = 1; t < NT; ++t)
 #pragma unroll
-        for (int t = 1; t < NT; ++t) mt = fmaxf(fmaxf(mt, mx[t][0]), mx[t][1]);
+          for (int i = 0; i < 16; i += 2) mt = fmaxf(fmaxf(mt, sc[t][i]), sc[t][i + 1]);
         mt = pair_max(mt);
-        const bool upd = seen ? mt > 0.f : mt > 0.5f * MASK_NEG;
-        if (__any(upd)) {
+        if (__any(mt > m)) {
           // the running maximum moves (rare after the first tiles): rescale what is accumulated
-          const float delta = upd ? mt : 0.f;
-          const float alpha = seen ? __builtin_amdgcn_exp2f(-delta) : 0.f;  // nothing accumulated before
+          const float m_new = fmaxf(m, mt);
+          const float alpha = __builtin_amdgcn_exp2f(m - m_new);
           l *= alpha;
 #pragma unroll
           for (int i = 0; i < 16; ++i) o[i] *= alpha;
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sc[t][i] -= delta;
-          const float nm = negm[0] - delta;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) negm[i] = nm;
-          seen = seen || upd;
+          m = m_new;
         }
-        // P = exp2(s - m); its bf16 image is both the PV operand and (summed by dot2 against
-        // ones) the denominator, so numerator and denominator see the same rounded weights
+        float ps = 0.f;
         bf16x8 pf[NT][2];
-        float lp[4] = {l, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-          for (int i = 0; i < 16; i += 2) {
-            bf16x2 pk;
-            pk[0] = (__bf16)__builtin_amdgcn_exp2f(sc[t][i]);
-            pk[1] = (__bf16)__builtin_amdgcn_exp2f(sc[t][i + 1]);
-            bf16x2 ones;
-            ones[0] = (__bf16)1.0f;
-            ones[1] = (__bf16)1.0f;
-            lp[(i >> 1) & 3] = __builtin_amdgcn_fdot2_f32_bf16(pk, ones, lp[(i >> 1) & 3], false);
-            pf[t][i >> 3][i & 7] = pk[0];
-            pf[t][i >> 3][(i & 7) + 1] = pk[1];
+          for (int i = 0; i < 16; ++i) {
+            const float e = __builtin_amdgcn_exp2f(sc[t][i] - m);
+            ps += e;
+            pf[t][i >> 3][i & 7] = (__bf16)e;
           }
-        l = (lp[0] + lp[1]) + (lp[2] + lp[3]);
-        // next pair's K fragments (clamped at the end: the last read is harmless and unused)
-        {
-          const int kn = kt + NT;
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            const int kk = kn + t < nkt ? kn + t : nkt - 1;
-            kf[t][0] = kl[(kk * 2 + 0) * 64];
-            kf[t][1] = kl[(kk * 2 + 1) * 64];
-          }
-        }
+        l += ps;
         // O^T[dim, query] += V^T[dim, key] P^T[key, query]; P^T is the accumulator as B operand
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -980,12 +938,6 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(QkvAttnParams p) {
     }
   };
 
-#ifndef SSKD_QA_LATE_PRIO
-#define SSKD_QA_LATE_PRIO 1
-#endif
-  // the second-dispatched half loses every age-based issue arbitration against its SIMD partner;
-  // one static priority bump evens the two halves out (they meet at a barrier every step)
-  if (late && SSKD_QA_LATE_PRIO) __builtin_amdgcn_s_setprio(SSKD_QA_LATE_PRIO);
   for (int k = 0; k <= p.hpw; ++k) {
     const bool has_p1 = k < p.hpw, has_p2 = k >= 1;
     SSKD_QA_STAMP(k, 0);
