@@ -28,7 +28,8 @@ def synthetic_ids(batch: int, seq_len: int, vocab: int, device, seed: int = 0):
     return ids, torch.ones_like(ids)
 
 
-def bench_encode(device, world: int, steps: int, warmup: int, barrier, batch: int = 512, seq_len: int = 256):
+def bench_encode(device, world: int, steps: int, warmup: int, barrier, batch: int = 512, seq_len: int = 256,
+                 ragged: bool = True):
     """docs embedded / s: every rank encodes its own ``batch x seq_len`` synthetic batches
     (pure data parallel, no communication); whole-job rate = world * batch * steps / max-rank time."""
     import torch.distributed as dist
@@ -69,6 +70,58 @@ def bench_encode(device, world: int, steps: int, warmup: int, barrier, batch: in
             "algorithmic_flops_per_step": flops,
         },
         "unit_norm_ok": bool(torch.allclose(norms, torch.ones_like(norms), atol=1e-3)),
+        # rank 0's own rate on MS MARCO-shaped ragged lengths (per GPU, not aggregated)
+        "ragged": bench_encode_ragged(enc, device) if ragged else None,
+    }
+
+
+def marco_like_lengths(n: int, seed: int = 7, max_len: int = 256) -> np.ndarray:
+    """Token lengths of an MS MARCO-shaped passage set (clipped log-normal, mean ~75,
+    median ~68, max 256 - an assumption of the survey, not pinned by the reference)."""
+    rng = np.random.default_rng(seed)
+    lens = rng.lognormal(mean=np.log(68.0), sigma=0.45, size=n)
+    return np.clip(np.rint(lens), 8, max_len).astype(np.int64)
+
+
+def bench_encode_ragged(enc: Mi355xSentenceEncoder, device, passes: int = 3, n_docs: int = 8192, batch: int = 512):
+    """docs/s on ragged lengths the way ``encode()`` runs them: sort by length (longest first),
+    batches of ``batch``, each padded to its longest member (rounded up to the 32-token tile).
+    FLOPs are counted on real tokens only."""
+    cfg = enc.config
+    lens = np.sort(marco_like_lengths(n_docs))[::-1]
+    g = torch.Generator(device=device).manual_seed(11)
+    batches = []
+    flops = 0.0
+    for b0 in range(0, n_docs, batch):
+        bl = lens[b0:b0 + batch]
+        S = int(-(-int(bl[0]) // 32) * 32)
+        ids = torch.randint(999, cfg.vocab_size, (len(bl), S), generator=g, device=device, dtype=torch.int32)
+        ids[:, 0] = 101
+        lt = torch.from_numpy(bl.copy()).to(device)
+        mask = (torch.arange(S, device=device)[None, :] < lt[:, None]).to(torch.int32)
+        ids = ids * mask
+        batches.append((ids, mask, torch.empty((len(bl), cfg.hidden_size), dtype=torch.float32, device=device)))
+        flops += float(sum(encoder_flops(int(l), int(l), cfg) for l in bl))
+    def one_pass():
+        for ids, mask, out in batches:
+            enc.encode_token_ids(ids, mask, normalize=True, out=out)
+    one_pass()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        one_pass()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / passes
+    padded = sum(int(i.numel()) for i, _, _ in batches)
+    return {
+        "value": round(n_docs / dt, 1),
+        "unit": "docs/s",
+        "workload": f"{n_docs} passages, lengths clipped log-normal (mean {lens.mean():.0f}, median "
+                    f"{int(np.median(lens))}, max {int(lens.max())} tokens; SURVEY.md §8d assumption), "
+                    f"length-sorted batches of {batch} padded to the longest member",
+        "real_tokens_per_s": round(float(lens.sum()) / dt, 1),
+        "padding_overhead": round(padded / float(lens.sum()) - 1.0, 4),
+        "mfma_frac_real_tokens": round(flops / dt / 1e12 / MFMA_BF16_PEAK_TF, 4),
     }
 
 

@@ -683,6 +683,7 @@ struct QkvAttnParams {
   int S;
   int nkt;              // S_pad / 32
   int hpw;              // heads per workgroup (divides 12)
+  int spw;              // sequences per workgroup: 8 / nkt when nkt <= 4 (short sequences), else 1
   float q_scale;        // log2(e) / sqrt(32)
   __bf16* ctx;          // fragment-order [T_pad, 384]
 };
@@ -723,40 +724,48 @@ __device__ unsigned long long g_probe_qa[16][8];
 template <bool TWO_TILES>
 __global__ __launch_bounds__(512) void qkv_attention_kernel(QkvAttnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char qa_lds[];
-  // [3 weight tiles: 72 KiB][2 x (K frags nkt*2 KiB, V frags nkt*2 KiB)][mask bias nkt*32 f32][bias 2 x 96 f32]
+  // T = spw * nkt token tiles live in the workgroup (<= 8, or nkt <= 16 in the TWO_TILES case)
+  // [3 weight tiles: 72 KiB][2 x (K frags T*2 KiB, V frags T*2 KiB)][mask bias T*32 f32][bias 2 x 96 f32]
+  const int T = p.spw * p.nkt;
   bf16x8* const wlds = reinterpret_cast<bf16x8*>(qa_lds);
-  bf16x8* const kvlds = wlds + 3 * WTILE_VEC;  // buffer i: K at i * nkt * 256, V at + nkt * 128
-  float* const mbias = reinterpret_cast<float*>(kvlds + (TWO_TILES ? 1 : 2) * p.nkt * 256);
-  float* const bias_lds = mbias + p.nkt * 32;
-  __shared__ int s_kmax;
-  __shared__ int s_partial[ATT_MAX_S / 32];
+  bf16x8* const kvlds = wlds + 3 * WTILE_VEC;  // buffer i: K at i * T * 256, V at + T * 128
+  float* const mbias = reinterpret_cast<float*>(kvlds + (TWO_TILES ? 1 : 2) * T * 256);
+  float* const bias_lds = mbias + T * 32;
+  __shared__ int s_kmax[8];                    // per sequence of the workgroup
+  __shared__ int s_partial[ATT_MAX_S / 32];    // per token tile of the workgroup
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool late = wave >= 4;
   const int r = lane & 31, h = lane >> 5;
-  // One workgroup = one batch row x `hpw` consecutive heads (hpw = 12 when there are enough rows
-  // to fill the chip: the row's activations are then read once and stay in registers).
+  // One workgroup = `spw` batch rows x `hpw` consecutive heads (hpw = 12 when there are enough
+  // rows to fill the chip: the rows' activations are then read once and stay in registers).
+  // Short sequences (nkt <= 4 tiles) are packed spw = 8 / nkt to a workgroup so that every wave
+  // has a query tile: wave = (sequence sl, tile tq_w) and its LDS tile slot is `wave` itself.
   const int groups = NH / p.hpw;
-  const int b = blockIdx.x / groups, head0 = (blockIdx.x - b * groups) * p.hpw;
+  const int bg = blockIdx.x / groups, head0 = (blockIdx.x - bg * groups) * p.hpw;
   const int S = p.S, nkt = p.nkt;
+  const int sl = TWO_TILES ? 0 : wave / nkt;
+  const int tq_w = wave - sl * nkt;
+  const bool active = TWO_TILES || (sl < p.spw && bg * p.spw + sl < p.B);
+  const int b = bg * p.spw + (active ? sl : 0);
 
-  if (tid == 0) s_kmax = 0;
+  if (tid < 8) s_kmax[tid] = 0;
   if (tid < ATT_MAX_S / 32) s_partial[tid] = 0;
   __syncthreads();
-  int local_max = 0;
-  for (int i = tid; i < nkt * 32; i += 512) {
-    const bool on = i < S && p.mask[(int64_t)b * S + i] != 0;
+  for (int i = tid; i < T * 32; i += 512) {  // at most one position per thread (T * 32 <= 512)
+    const int si = i / (nkt * 32), pos = i - si * (nkt * 32);
+    const int bi = bg * p.spw + si;
+    const bool on = bi < p.B && pos < S && p.mask[(int64_t)bi * S + pos] != 0;
     mbias[i] = on ? 0.f : MASK_NEG;
-    if (on) local_max = i / 32 + 1;
+    if (on) atomicMax(&s_kmax[si], pos / 32 + 1);
     else s_partial[i / 32] = 1;
   }
-  if (local_max) atomicMax(&s_kmax, local_max);
 
   // activations of this wave's token tile: resident for every head (single-tile case)
   bf16x8 x0[KSTEPS];
   if (!TWO_TILES) {
-    const int tq = wave < nkt ? wave : 0;
+    const int tq = active ? tq_w : 0;
     const bf16x8* xs = p.x + frag_base((int64_t)b * nkt + tq, 0, KSTEPS) + lane;
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) x0[s] = xs[s * 64];
@@ -824,8 +833,8 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(QkvAttnParams p) {
         vf[i >> 3][i & 7] = (__bf16)(av[i] + bv);
       }
     }
-    bf16x8* kl = kvlds + buf * nkt * 256;
-    bf16x8* vl = kl + nkt * 128;
+    bf16x8* kl = kvlds + buf * T * 256;
+    bf16x8* vl = kl + T * 128;
     kl[(tq * 2 + 0) * 64 + lane] = kf[0];
     kl[(tq * 2 + 1) * 64 + lane] = kf[1];
     vl[(tq * 2 + 0) * 64 + lane] = vf[0];
@@ -833,7 +842,7 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(QkvAttnParams p) {
   };
   auto project_all = [&](int buf) {
     if (!TWO_TILES) {
-      if (wave < nkt) project(x0, 0, wave, buf);
+      if (active) project(x0, 0, wave, buf);  // LDS tile slot = sl * nkt + tq_w = wave
     } else {
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
@@ -849,13 +858,17 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(QkvAttnParams p) {
   };
 
   // ---- attention of this wave's query tiles for `head`, K / V from LDS buffer `buf` ------------
-  auto attend = [&](int head, int buf, int kmax) {
-    const bf16x8* kl = kvlds + buf * nkt * 256 + lane;
-    const bf16x8* vl = kl + nkt * 128;
+  auto attend = [&](int head, int buf) {
+    // K / V fragments, mask bias and flags of this wave's own sequence
+    const bf16x8* kl = kvlds + buf * T * 256 + sl * nkt * 128 + lane;
+    const bf16x8* vl = kl + T * 128;
+    const float* mb_seq = mbias + sl * nkt * 32;
+    const int* partial_seq = s_partial + sl * nkt;
+    const int kmax = s_kmax[sl];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      const int qt = wave + 8 * u;
-      if (qt >= nkt) break;
+      const int qt = (TWO_TILES ? wave : tq_w) + 8 * u;
+      if (TWO_TILES ? qt >= nkt : !active) break;
       const bf16x8 qf0 = qf_old[u][0], qf1 = qf_old[u][1];
       f32x16 o = zero16();
       float m = MASK_NEG, l = 0.f;
@@ -879,10 +892,10 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(QkvAttnParams p) {
         // sc[t][4g + e] = score(key 32(kt + t) + 8g + 4h + e, query = lane), in log2 units
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          if (s_partial[kt + t]) {  // only tiles with masked / padding keys pay for the bias
+          if (partial_seq[kt + t]) {  // only tiles with masked / padding keys pay for the bias
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-              const f32x4 mb = *reinterpret_cast<const f32x4*>(&mbias[(kt + t) * 32 + 8 * g + 4 * h]);
+              const f32x4 mb = *reinterpret_cast<const f32x4*>(&mb_seq[(kt + t) * 32 + 8 * g + 4 * h]);
 #pragma unroll
               for (int e = 0; e < 4; ++e) sc[t][4 * g + e] += mb[e];
             }
@@ -952,7 +965,6 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(QkvAttnParams p) {
     __syncthreads();
     SSKD_QA_STAMP(k, 3);
     if (k + 1 < p.hpw) load_weights(head0 + k + 1);
-    const int kmax = s_kmax;
     SSKD_QA_STAMP(k, 4);
     if (TWO_TILES) {
       // S > 256: double-buffered K / V would not fit LDS -> plain schedule, one buffer
@@ -964,16 +976,16 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(QkvAttnParams p) {
           qf_old[u][0] = qf_new[u][0];
           qf_old[u][1] = qf_new[u][1];
         }
-        attend(head0 + k, 0, kmax);
+        attend(head0 + k, 0);
       }
       continue;
     }
     if (!late) {
       if (has_p1) project_all(k & 1);
       SSKD_QA_STAMP(k, 5);
-      if (has_p2) attend(head0 + k - 1, (k - 1) & 1, kmax);
+      if (has_p2) attend(head0 + k - 1, (k - 1) & 1);
     } else {
-      if (has_p2) attend(head0 + k - 1, (k - 1) & 1, kmax);
+      if (has_p2) attend(head0 + k - 1, (k - 1) & 1);
       SSKD_QA_STAMP(k, 5);
       if (has_p1) project_all(k & 1);
     }
@@ -1144,15 +1156,19 @@ int run_layers(const sskd_encoder_config* cfg, const sskd_encoder_weights* w, co
     qa.nkt = nkt;
     qa.q_scale = LOG2E / sqrtf((float)DH);
     qa.ctx = ws.ctx;
+    // short sequences: several to a workgroup, so that all 8 waves own a query tile
+    qa.spw = nkt <= 4 ? 8 / nkt : 1;
+    const int qa_tiles = qa.spw * nkt;
+    const int qa_rows = (B + qa.spw - 1) / qa.spw;  // workgroup rows
     const size_t qa_lds_bytes = 3 * WTILE_VEC * sizeof(bf16x8) +
-                                (size_t)nkt * ((nkt > 8 ? 2 : 4) * 128 * sizeof(bf16x8) + 32 * sizeof(float)) + 2 * 96 * sizeof(float);
+                                (size_t)qa_tiles * ((nkt > 8 ? 2 : 4) * 128 * sizeof(bf16x8) + 32 * sizeof(float)) + 2 * 96 * sizeof(float);
     auto qa_kernel = nkt > 8 ? qkv_attention_kernel<true> : qkv_attention_kernel<false>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(qa_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)qa_lds_bytes);
     // all 12 heads per workgroup once there are enough batch rows to fill the chip; fewer heads
     // per workgroup (more workgroups) for small batches
-    qa.hpw = B >= 256 ? 12 : (B >= 64 ? 4 : 1);
-    hipLaunchKernelGGL(qa_kernel, dim3(B * (NH / qa.hpw)), dim3(512), qa_lds_bytes, st, qa);
+    qa.hpw = qa_rows >= 256 ? 12 : (qa_rows >= 64 ? 4 : 1);
+    hipLaunchKernelGGL(qa_kernel, dim3(qa_rows * (NH / qa.hpw)), dim3(512), qa_lds_bytes, st, qa);
     if ((rc = sskd::check_launch("qkv_attention_kernel")) != SSKD_OK) return rc;
 
     GemmN384Params o{};

@@ -110,6 +110,28 @@ def test_encoder_shapes_and_ragged_masks(enc_l2, B, S, lengths):
     assert np.abs(emb - want).max() <= EMB_ATOL
 
 
+@pytest.mark.parametrize("S", [32, 64, 96, 128, 160])
+def test_short_sequences_packed_per_workgroup(enc_l2, S):
+    """Sequences of <= 4 token tiles share an attention workgroup (8 / tiles of them): odd batch
+    sizes, ragged lengths, and no dependence on which sequences share the workgroup."""
+    enc, cfg, sd = enc_l2
+    B = 19
+    rng = np.random.default_rng(S)
+    lengths = [int(x) for x in rng.integers(2, S + 1, size=B)]
+    lengths[0] = S
+    ids, mask = enc_oracle.synthetic_token_ids(B, S, seed=500 + S, lengths=lengths)
+    emb = enc.encode_token_ids(ids, mask).cpu().numpy()
+    want = enc_oracle.encode_token_ids(sd, ids, mask, cfg.num_hidden_layers)
+    assert _cos(emb, want).min() >= COS_MIN
+    assert np.abs(emb - want).max() <= EMB_ATOL
+    # the same rows in another order / another batch land in other workgroup slots: identical bits
+    perm = rng.permutation(B)
+    emb_p = enc.encode_token_ids(ids[perm], mask[perm]).cpu().numpy()
+    assert np.array_equal(emb_p, emb[perm])
+    alone = enc.encode_token_ids(ids[5:6], mask[5:6]).cpu().numpy()
+    assert np.array_equal(alone[0], emb[5])
+
+
 def test_padding_invariance(enc_l2):
     """An embedding must not depend on batch-mates or on how far the row is padded."""
     enc, cfg, sd = enc_l2
