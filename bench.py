@@ -96,6 +96,7 @@ def main() -> None:
     ap.add_argument("--queries", type=int, default=N_QUERIES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encode", action="store_true")
+    ap.add_argument("--no-ragged", action="store_true", help="skip the ragged-length encode leg")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -250,7 +251,8 @@ def main() -> None:
         except ImportError:
             bench_encode = None
         if bench_encode is not None:
-            line["encode"] = bench_encode(dev, world, args.steps, args.warmup, barrier)
+            line["encode"] = bench_encode(dev, world, args.steps, args.warmup, barrier,
+                                          ragged=not args.no_ragged and rank == 0)
 
     # ---- CPU baseline: rank 0, N = 1 only --------------------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
