@@ -496,6 +496,77 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(MergeParams<IdT> p) {
   }
 }
 
+// ------------------------------------------------------------------------- //
+// group reduce: one wave per (query, group of `lpg` consecutive lists).  The group's candidates
+// (<= 1024) are loaded once and its best k are picked in registers; the output has the layout of
+// the input ([query][list][k], sorted lists, (-FLT_MAX, -1) padding), so the step can be repeated.
+// It keeps the single-wave final merge short when few queries are spread over many slices
+// (one query over 1 M rows leaves > 4000 per-lane lists).
+// ------------------------------------------------------------------------- //
+constexpr int REDUCE_CPL = 16;               // candidates per lane
+constexpr int REDUCE_MAX_CAND = 64 * REDUCE_CPL;
+constexpr int MERGE_DIRECT_MAX_LISTS = 64;   // the final merge reads its candidates from memory
+
+struct ReduceParams {
+  const float* scores;  // [nq][lists_in][k]
+  const int* ids;
+  int k;
+  int lists_in;
+  int lpg;              // lists per group, lpg * k <= REDUCE_MAX_CAND
+  int groups;
+  int nq;
+  float* out_scores;    // [nq][groups][k]
+  int* out_ids;
+};
+
+__global__ __launch_bounds__(256) void reduce_lists_kernel(ReduceParams p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= (int64_t)p.nq * p.groups) return;
+  const int q = (int)(w / p.groups), g = (int)(w - (int64_t)q * p.groups);
+  const int first = g * p.lpg;
+  const int n_lists = min(p.lpg, p.lists_in - first);
+  const int n_cand = n_lists * p.k;
+  const int64_t base = ((int64_t)q * p.lists_in + first) * p.k;
+  float cs[REDUCE_CPL];
+  int ci[REDUCE_CPL];
+#pragma unroll
+  for (int j = 0; j < REDUCE_CPL; ++j) {
+    const int c = lane + 64 * j;
+    const bool in = c < n_cand;
+    ci[j] = in ? p.ids[base + c] : -1;
+    cs[j] = in ? p.scores[base + c] : -FLT_MAX;
+  }
+  const int64_t ob = ((int64_t)q * p.groups + g) * p.k;
+  for (int r = 0; r < p.k; ++r) {
+    float best_s = -INFINITY;
+    int best_i = -1;
+#pragma unroll
+    for (int j = 0; j < REDUCE_CPL; ++j)
+      if (ci[j] >= 0 && (best_i < 0 || cs[j] > best_s || (cs[j] == best_s && ci[j] < best_i))) {
+        best_s = cs[j];
+        best_i = ci[j];
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float os = __shfl_xor(best_s, o);
+      const int oi = __shfl_xor(best_i, o);
+      if (oi >= 0 && (best_i < 0 || os > best_s || (os == best_s && oi < best_i))) {
+        best_s = os;
+        best_i = oi;
+      }
+    }
+    if (lane == 0) {
+      p.out_scores[ob + r] = best_i >= 0 ? best_s : -FLT_MAX;
+      p.out_ids[ob + r] = best_i;
+    }
+    // row ids are unique among a query's candidates: retire the winner wherever it lives
+#pragma unroll
+    for (int j = 0; j < REDUCE_CPL; ++j)
+      if (ci[j] == best_i) ci[j] = -1;
+  }
+}
+
 __global__ __launch_bounds__(256) void fill_int_kernel(int* p, int n, int v) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) p[i] = v;
@@ -553,8 +624,10 @@ struct Plan {
   int tiles_per_slice;
   int n_tiles;
   int lists_per_query;
-  int passes;     // scan passes (k > SSKD_K_PASS is served by chaining)
+  int passes;     // scan passes of K results each (k > K is served by chaining)
   size_t part_elems;
+  int reduce_lpg;       // lists per group of a reduce step
+  size_t reduce_elems;  // elements of one reduce buffer (0: no reduce step needed); two are kept
 };
 
 int env_int(const char* name, int dflt) {
@@ -567,7 +640,12 @@ Plan make_plan(int64_t n_rows, int nq, int k) {
   pl.n_tiles = (int)sskd::ceil_div(n_rows, TILE_ROWS);
   const int kk = k < SSKD_K_PASS ? k : SSKD_K_PASS;
   pl.K = kk <= 10 ? 10 : (kk <= 16 ? 16 : 32);
-  pl.passes = (int)sskd::ceil_div(k, SSKD_K_PASS);
+  // k > SSKD_K_PASS is served by chained passes of K results each (a pass returns exactly the next
+  // K in rank order because no list can hold more than K of them).  With a handful of queries a
+  // wave sees only a few tiles, filling 32-deep lists dominates a pass (5 ms against 1.4 ms for
+  // K = 10 at 1 M rows), and more passes of the light kernel win.
+  if (k > SSKD_K_PASS && nq <= 64) pl.K = 10;
+  pl.passes = (int)sskd::ceil_div(k, pl.K);
   pl.waves = 8;
   int qb = nq > 32 ? 2 : 1;
   const int qb_env = env_int("SSKD_SCAN_QB", 0);
@@ -577,7 +655,9 @@ Plan make_plan(int64_t n_rows, int nq, int k) {
   pl.n_qblocks = (int)sskd::ceil_div(nq, 32 * qb);
   // enough workgroups to fill 256 CUs several times over; slices in multiples
   // of 8 so that blockIdx % 8 (the XCD label) is a function of the slice
-  const int target_wgs = env_int("SSKD_SCAN_TARGET_WGS", 1024);
+  // (a couple of query blocks - the online /search shape - want one or two workgroups per CU
+  // with many tiles each, not a thousand short ones)
+  const int target_wgs = env_int("SSKD_SCAN_TARGET_WGS", pl.n_qblocks <= 2 ? 512 : 1024);
   int slices = (int)sskd::ceil_div(target_wgs, pl.n_qblocks);
   slices = (int)sskd::ceil_div(slices, 8) * 8;
   const int max_slices = (int)sskd::ceil_div(pl.n_tiles, pl.waves);  // >= 1 tile per wave
@@ -587,6 +667,11 @@ Plan make_plan(int64_t n_rows, int nq, int k) {
   pl.n_slices = (int)sskd::ceil_div(pl.n_tiles > 0 ? pl.n_tiles : 1, pl.tiles_per_slice);
   pl.lists_per_query = pl.n_slices * pl.waves * 2;
   pl.part_elems = (size_t)nq * pl.lists_per_query * pl.K;
+  // group-reduce steps before the final merge (see reduce_lists_kernel)
+  pl.reduce_lpg = REDUCE_MAX_CAND / pl.K;
+  pl.reduce_elems = pl.lists_per_query > MERGE_DIRECT_MAX_LISTS
+                        ? (size_t)nq * sskd::ceil_div(pl.lists_per_query, pl.reduce_lpg) * pl.K
+                        : 0;
   return pl;
 }
 
@@ -671,7 +756,8 @@ size_t sskd_index_search_workspace_bytes(int64_t n_rows, int nq, int k) {
   const Plan pl = make_plan(n_rows, nq, k);
   return align256(pl.part_elems * sizeof(float)) + align256(pl.part_elems * sizeof(int)) +
          align256((size_t)nq * sizeof(float)) + align256((size_t)nq * sizeof(int)) +
-         align256((size_t)nq * (1 + pl.K) * sizeof(int));
+         align256((size_t)nq * (1 + pl.K) * sizeof(int)) +
+         2 * (align256(pl.reduce_elems * sizeof(float)) + align256(pl.reduce_elems * sizeof(int)));
 }
 
 int sskd_index_search_plan(int64_t n_rows, int nq, int k, int* queries_per_block,
@@ -728,6 +814,15 @@ int sskd_index_search_profiled(const float* d_tiled, int64_t n_rows, const float
   int* ub_ids = reinterpret_cast<int*>(ws);
   ws += align256((size_t)nq * sizeof(int));
   int* tau = reinterpret_cast<int*>(ws);
+  ws += align256((size_t)nq * (1 + pl.K) * sizeof(int));
+  float* red_scores[2];
+  int* red_ids[2];
+  for (int i = 0; i < 2; ++i) {
+    red_scores[i] = reinterpret_cast<float*>(ws);
+    ws += align256(pl.reduce_elems * sizeof(float));
+    red_ids[i] = reinterpret_cast<int*>(ws);
+    ws += align256(pl.reduce_elems * sizeof(int));
+  }
 
   ScanParams sp{};
   sp.tiled = d_tiled;
@@ -752,19 +847,41 @@ int sskd_index_search_profiled(const float* d_tiled, int64_t n_rows, const float
     int rc = pass == 0 ? dispatch_scan<false>(pl, sp, st) : dispatch_scan<true>(pl, sp, st);
     if (pass == 0 && ev_scan_end) (void)hipEventRecord(static_cast<hipEvent_t>(ev_scan_end), st);
     if (rc != SSKD_OK) return rc;
+    const float* cand_scores = part_scores;
+    const int* cand_ids = part_ids;
+    int lists = pl.lists_per_query;
+    for (int step = 0; lists > MERGE_DIRECT_MAX_LISTS; ++step) {
+      ReduceParams rp{};
+      rp.scores = cand_scores;
+      rp.ids = cand_ids;
+      rp.k = pl.K;
+      rp.lists_in = lists;
+      rp.lpg = pl.reduce_lpg;
+      rp.groups = (int)sskd::ceil_div(lists, pl.reduce_lpg);
+      rp.nq = nq;
+      rp.out_scores = red_scores[step & 1];
+      rp.out_ids = red_ids[step & 1];
+      hipLaunchKernelGGL(reduce_lists_kernel, dim3((unsigned)sskd::ceil_div((int64_t)nq * rp.groups, 4)),
+                         dim3(256), 0, st, rp);
+      rc = sskd::check_launch("reduce_lists_kernel");
+      if (rc != SSKD_OK) return rc;
+      cand_scores = rp.out_scores;
+      cand_ids = rp.out_ids;
+      lists = rp.groups;
+    }
     MergeParams<int> mp{};
-    mp.scores = part_scores;
-    mp.ids = part_ids;
+    mp.scores = cand_scores;
+    mp.ids = cand_ids;
     mp.list_stride = pl.K;
-    mp.q_stride = (int64_t)pl.lists_per_query * pl.K;
+    mp.q_stride = (int64_t)lists * pl.K;
     mp.k_in = pl.K;
-    mp.n_cand = pl.lists_per_query * pl.K;
+    mp.n_cand = lists * pl.K;
     mp.nq = nq;
     mp.out_scores = d_out_scores;
     mp.out_ids = d_out_ids;
     mp.out_stride = k;
-    mp.out_off = pass * SSKD_K_PASS;
-    mp.count = (k - pass * SSKD_K_PASS) < SSKD_K_PASS ? (k - pass * SSKD_K_PASS) : SSKD_K_PASS;
+    mp.out_off = pass * pl.K;
+    mp.count = (k - pass * pl.K) < pl.K ? (k - pass * pl.K) : pl.K;
     mp.id_offset = id_offset;
     mp.ub_scores = (pass + 1 < pl.passes) ? ub_scores : nullptr;
     mp.ub_ids = ub_ids;
