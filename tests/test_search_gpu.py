@@ -5,6 +5,8 @@ scores AND ids must be identical.  ``topk_blas`` (numpy ``q @ c.T`` + argsort, t
 idiom src/kd/eval.py:86) is the second witness: scores within 1e-3 (north star tolerance; in
 practice < 1e-6) and identical ids outside near-ties.
 """
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -100,6 +102,22 @@ def test_large_k_chained_passes(gpu, native_lib, k):
     _check_exact(native_lib, corpus, queries, k)
     # fewer rows than k: tail is padding
     _check_exact(native_lib, corpus[:70], queries, k)
+
+
+@pytest.mark.parametrize("nq,k", [(1, 10), (1, 50), (1, 100), (1, 200), (3, 33), (40, 64), (64, 100), (65, 100)])
+def test_online_shapes_few_queries_many_slices(gpu, native_lib, nq, k):
+    """The /search shape (schemas.py:12-16: one query, k <= 100, rerank_top_k <= 200): a few queries
+    are spread over hundreds of slices, so the group-reduce steps and (for k > 32 with <= 64
+    queries) the chained K = 10 passes carry the result."""
+    n = 150_000
+    corpus = oracle.seeded_unit_rows(n, 384, 77)
+    queries = oracle.seeded_unit_rows(nq, 384, 78)
+    # plant near-duplicates so that several of the best rows share a per-lane list
+    corpus[1000:1012] = oracle.l2_normalize_rows(queries[0][None, :] + 0.05 * corpus[1000:1012])
+    _check_exact(native_lib, corpus, queries, k)
+    plan = [ctypes.c_int() for _ in range(5)]
+    _native.check(native_lib.sskd_index_search_plan(n, nq, k, *[ctypes.byref(x) for x in plan]))
+    assert plan[2].value >= 64  # many slices
 
 
 def test_ties_resolve_to_lower_id(gpu, native_lib):
