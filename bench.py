@@ -111,6 +111,11 @@ def main() -> None:
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        # RCCL builds its communicator lazily on the first collective: do that here, outside any
+        # timed region (it is not part of a search step), whatever --warmup is
+        _probe = torch.zeros(world * 4, device=dev)
+        dist.all_gather_into_tensor(_probe, torch.ones(4, device=dev))
+        torch.cuda.synchronize()
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import semantic_search_kd_amd as pkg
