@@ -44,8 +44,12 @@ def test_search_plan_reports_geometry(native_lib):
     assert qpb.value in (32, 64) and waves.value == 8 and scans.value == 1
     assert passes.value == -(-10_000 // qpb.value)
     assert slices.value % 8 == 0
-    rc = native_lib.sskd_index_search_plan(1000, 1, 100, qpb, passes, slices, waves, scans)
+    # k > 32 is served by chained passes: 32 results per pass for many queries, 10 per pass (the
+    # light kernel) when there are at most 64 queries
+    rc = native_lib.sskd_index_search_plan(1_000_000, 10_000, 100, qpb, passes, slices, waves, scans)
     assert rc == 0 and scans.value == 4 and qpb.value == 32
+    rc = native_lib.sskd_index_search_plan(1000, 1, 100, qpb, passes, slices, waves, scans)
+    assert rc == 0 and scans.value == 10 and qpb.value == 32
 
 
 def test_invalid_arguments_are_reported_not_thrown(native_lib):
