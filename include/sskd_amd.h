@@ -106,6 +106,21 @@ int sskd_index_search_profiled(const float* d_tiled, int64_t n_rows,
                                void* d_workspace, size_t workspace_bytes, void* stream,
                                void* ev_scan_begin, void* ev_scan_end);
 
+/* One-pass variant for the online shape (reference: src/serve/app.py:285-301, schemas.py:12-16 -
+ * one query, k <= 100, rerank_top_k <= 200).  sskd_index_search serves k > SSKD_K_PASS by chained
+ * corpus passes; this entry point scans the corpus ONCE with plain per-lane lists, collects the best
+ * k candidates and PROVES them exact where it can: a row is missing from the candidates only if its
+ * list was full and it ranks after that list's last entry, so if the k-th best candidate ranks at or
+ * before the best such last entry, the result is the exact top k.  *d_inexact (device int) is set
+ * to 0 when every query's result is proven, to 1 otherwise - the caller then falls back to
+ * sskd_index_search (results are never silently approximate).  Limits: 1 <= nq <= 64,
+ * 1 <= k <= 256, n_rows >= 1.  Outputs as sskd_index_search; stream-ordered, no host sync. */
+size_t sskd_index_search_onepass_workspace_bytes(int64_t n_rows, int nq, int k);
+int sskd_index_search_onepass(const float* d_tiled, int64_t n_rows, const float* d_queries, int nq,
+                              int k, int64_t id_offset, float* d_out_scores, int64_t* d_out_ids,
+                              int* d_inexact, void* d_workspace, size_t workspace_bytes,
+                              void* stream);
+
 /* Launch geometry the search would use (for roofline accounting in bench.py):
  * queries per workgroup tile (B_q), corpus passes, slices, waves per workgroup,
  * and scan passes needed for this k. Any out pointer may be NULL. */

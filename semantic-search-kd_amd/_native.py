@@ -75,6 +75,8 @@ SIGNATURES = {
     "sskd_index_search": (_i, [_vp, _i64, _vp, _i, _i, _i64, _vp, _vp, _vp, _sz, _vp]),
     "sskd_index_search_profiled": (_i, [_vp, _i64, _vp, _i, _i, _i64, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     "sskd_index_search_plan": (_i, [_i64, _i, _i, _ip, _ip, _ip, _ip, _ip]),
+    "sskd_index_search_onepass_workspace_bytes": (_sz, [_i64, _i, _i]),
+    "sskd_index_search_onepass": (_i, [_vp, _i64, _vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sskd_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "sskd_similarity": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
     "sskd_pool_normalize": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp]),

@@ -252,7 +252,10 @@ __device__ inline void compute_group(const float4 (&a)[GROUP], const float4* __r
   }
 }
 
-template <int K, int QB, int WAVES, bool HAS_UB>
+// POOLS = false: plain per-lane lists, no shared bound - then the ONLY reason a row is missing from
+// a query's candidates is that its own list was full of better rows, which is what the one-pass
+// search for k > K relies on (sskd_index_search_onepass).
+template <int K, int QB, int WAVES, bool HAS_UB, bool POOLS = true>
 __global__ __launch_bounds__(WAVES * 64) void scan_topk_kernel(ScanParams p) {
   extern __shared__ float4 qs[];  // [QB][96 chunks][32 queries]
   const int tid = threadIdx.x;
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(WAVES * 64) void scan_topk_kernel(ScanParams p) {
     const bool exchange = tiles_done < TAU_REFRESH_TILES ? (tiles_done & (tiles_done - 1)) == 0
                                                          : tiles_done % TAU_REFRESH_TILES == 0;
 #pragma unroll
-    for (int qq = 0; qq < QB; ++qq) {
+    for (int qq = 0; POOLS && qq < QB; ++qq) {
       const int w = wthr[qq * 32 + j];
       gthr[qq] = fmaxf(gthr[qq], ordered_to_float(w));
       if (exchange && real[qq]) {
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(WAVES * 64) void scan_topk_kernel(ScanParams p) {
               list[qq].insert(x, xid);
               // (a wave's first tile fills empty lists: nearly every row is taken, so only the
               // best of them is offered afterwards instead of all sixteen)
-              if (tiles_done > 0) {
+              if (POOLS && tiles_done > 0) {
                 const int xi = float_to_ordered(x);
                 if (pool_offer<K>(pool + (qq * 32 + j) * K, wthr + qq * 32 + j, xi) && real[qq])
                   (void)__hip_atomic_fetch_max(p.gpool + (int64_t)(q0 + qq * 32 + j) * K + xid % K, xi,
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(WAVES * 64) void scan_topk_kernel(ScanParams p) {
           }
         }
         // pick up what the pool learned (our own list's K-th entry is implied by it)
-        if (grew) {
+        if (POOLS && grew) {
           SSKD_COUNT(4, __popcll(__ballot(true)));
           if (tiles_done == 0)
             pool_offer<K>(pool + (qq * 32 + j) * K, wthr + qq * 32 + j,
@@ -519,14 +522,15 @@ constexpr int REDUCE_MAX_CAND = 64 * REDUCE_CPL;
 constexpr int MERGE_DIRECT_MAX_LISTS = 64;   // the final merge reads its candidates from memory
 
 struct ReduceParams {
-  const float* scores;  // [nq][lists_in][k]
+  const float* scores;  // [nq][lists_in][k]   (k entries per input list)
   const int* ids;
   int k;
+  int k_out;            // entries per output list (>= k when a wide result is collected)
   int lists_in;
   int lpg;              // lists per group, lpg * k <= REDUCE_MAX_CAND
   int groups;
   int nq;
-  float* out_scores;    // [nq][groups][k]
+  float* out_scores;    // [nq][groups][k_out]
   int* out_ids;
 };
 
@@ -548,8 +552,8 @@ __global__ __launch_bounds__(256) void reduce_lists_kernel(ReduceParams p) {
     ci[j] = in ? p.ids[base + c] : -1;
     cs[j] = in ? p.scores[base + c] : -FLT_MAX;
   }
-  const int64_t ob = ((int64_t)q * p.groups + g) * p.k;
-  for (int r = 0; r < p.k; ++r) {
+  const int64_t ob = ((int64_t)q * p.groups + g) * p.k_out;
+  for (int r = 0; r < p.k_out; ++r) {
     float best_s = -INFINITY;
     int best_i = -1;
 #pragma unroll
@@ -575,6 +579,83 @@ __global__ __launch_bounds__(256) void reduce_lists_kernel(ReduceParams p) {
 #pragma unroll
     for (int j = 0; j < REDUCE_CPL; ++j)
       if (ci[j] == best_i) ci[j] = -1;
+  }
+}
+
+// ------------------------------------------------------------------------- //
+// one-pass search for k > K (few queries): proof of exactness
+//
+// After a scan WITHOUT pools, a row is missing from a query's candidates only if its own list was
+// full and it ranks after that list's last entry.  Let E be the best-ranked last entry over the
+// query's FULL lists: every missing row ranks after E, so the candidates that rank at or before E
+// are exactly the global top of the ranking.  If the k-th best candidate ranks at or before E (or
+// no list is full), the candidates' top k is the exact answer.
+// ------------------------------------------------------------------------- //
+struct BoundParams {
+  const float* scores;  // [nq][lists][k] per-lane lists of the scan
+  const int* ids;
+  int k;
+  int lists;
+  int nq;
+  float* bound_s;       // [nq] E (score, id); id = -1: no list is full
+  int* bound_i;
+};
+
+__global__ __launch_bounds__(256) void last_entry_bound_kernel(BoundParams p) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= p.nq) return;
+  const int64_t base = (int64_t)q * p.lists * p.k + (p.k - 1);
+  float bs = -INFINITY;
+  int bi = -1;
+  for (int l = lane; l < p.lists; l += 64) {
+    const int ci = p.ids[base + (int64_t)l * p.k];
+    if (ci < 0) continue;  // list not full: it dropped nothing
+    const float cs = p.scores[base + (int64_t)l * p.k];
+    if (bi < 0 || ranks_before(cs, ci, bs, bi)) { bs = cs; bi = ci; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float os = __shfl_xor(bs, o);
+    const int oi = __shfl_xor(bi, o);
+    if (oi >= 0 && (bi < 0 || ranks_before(os, oi, bs, bi))) { bs = os; bi = oi; }
+  }
+  if (lane == 0) {
+    p.bound_s[q] = bs;
+    p.bound_i[q] = bi;
+  }
+}
+
+struct FinalizeParams {
+  const float* scores;  // [nq][k] best candidates in rank order, (-FLT_MAX, -1) padded
+  const int* ids;
+  const float* bound_s;
+  const int* bound_i;
+  int k;
+  int nq;
+  int64_t id_offset;
+  float* out_scores;    // [nq][k]
+  int64_t* out_ids;
+  int* inexact;         // [1], pre-zeroed: set to 1 if some query's top k is not proven
+};
+
+__global__ __launch_bounds__(256) void finalize_onepass_kernel(FinalizeParams p) {
+  const int q = blockIdx.x;
+  for (int r = threadIdx.x; r < p.k; r += 256) {
+    const int64_t o = (int64_t)q * p.k + r;
+    const int ci = p.ids[o];
+    p.out_scores[o] = ci >= 0 ? p.scores[o] : -FLT_MAX;
+    p.out_ids[o] = ci >= 0 ? (int64_t)ci + p.id_offset : -1;
+  }
+  if (threadIdx.x == 0) {
+    const int bi = p.bound_i[q];
+    if (bi >= 0) {
+      const int64_t o = (int64_t)q * p.k + (p.k - 1);
+      const int ci = p.ids[o];
+      const float cs = p.scores[o], bs = p.bound_s[q];
+      const bool proven = ci >= 0 && (cs > bs || (cs == bs && ci <= bi));
+      if (!proven) atomicExch(p.inexact, 1);
+    }
   }
 }
 
@@ -693,6 +774,16 @@ void launch_scan(const Plan& pl, const ScanParams& sp, hipStream_t st) {
   constexpr int WAVES = 8;
   const size_t lds = (size_t)QB * 32 * CHUNKS * sizeof(float4) + (size_t)QB * 32 * (K + 1) * sizeof(int);
   auto kern = scan_topk_kernel<K, QB, WAVES, HAS_UB>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3(pl.n_qblocks * pl.n_slices), dim3(WAVES * 64), lds, st, sp);
+}
+
+template <int QB>
+void launch_scan_plain(const Plan& pl, const ScanParams& sp, hipStream_t st) {
+  constexpr int WAVES = 8, K = 10;
+  const size_t lds = (size_t)QB * 32 * CHUNKS * sizeof(float4) + (size_t)QB * 32 * (K + 1) * sizeof(int);
+  auto kern = scan_topk_kernel<K, QB, WAVES, false, false>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kern, dim3(pl.n_qblocks * pl.n_slices), dim3(WAVES * 64), lds, st, sp);
@@ -866,6 +957,7 @@ int sskd_index_search_profiled(const float* d_tiled, int64_t n_rows, const float
       rp.scores = cand_scores;
       rp.ids = cand_ids;
       rp.k = pl.K;
+      rp.k_out = pl.K;
       rp.lists_in = lists;
       rp.lpg = pl.reduce_lpg;
       rp.groups = (int)sskd::ceil_div(lists, pl.reduce_lpg);
@@ -902,6 +994,136 @@ int sskd_index_search_profiled(const float* d_tiled, int64_t n_rows, const float
     if (rc != SSKD_OK) return rc;
   }
   return SSKD_OK;
+}
+
+namespace {
+constexpr int ONEPASS_MAX_NQ = 64, ONEPASS_MAX_K = 256;
+
+// plan of the one-pass search: the K = 10 geometry of a k = 10 search
+Plan onepass_plan(int64_t n_rows, int nq) { return make_plan(n_rows, nq, 10); }
+
+// reduce levels: per-lane lists (10 each) -> [groups][k] -> ... -> [1][k]
+size_t onepass_reduce_elems(const Plan& pl, int nq, int k) {
+  const int g1 = (int)sskd::ceil_div(pl.lists_per_query, REDUCE_MAX_CAND / pl.K);
+  return (size_t)nq * g1 * k;
+}
+}  // namespace
+
+size_t sskd_index_search_onepass_workspace_bytes(int64_t n_rows, int nq, int k) {
+  if (n_rows < 0 || nq <= 0 || nq > ONEPASS_MAX_NQ || k <= 0 || k > ONEPASS_MAX_K) return 0;
+  const Plan pl = onepass_plan(n_rows, nq);
+  const size_t re = onepass_reduce_elems(pl, nq, k);
+  return align256(pl.part_elems * sizeof(float)) + align256(pl.part_elems * sizeof(int)) +
+         2 * (align256(re * sizeof(float)) + align256(re * sizeof(int))) +
+         align256((size_t)nq * sizeof(float)) + align256((size_t)nq * sizeof(int));
+}
+
+int sskd_index_search_onepass(const float* d_tiled, int64_t n_rows, const float* d_queries, int nq,
+                              int k, int64_t id_offset, float* d_out_scores, int64_t* d_out_ids,
+                              int* d_inexact, void* d_workspace, size_t workspace_bytes,
+                              void* stream) {
+  SSKD_REQUIRE(n_rows >= 1, "index_search_onepass: empty index");
+  SSKD_REQUIRE(nq >= 1 && nq <= ONEPASS_MAX_NQ, "index_search_onepass: nq=%d outside [1, %d]", nq,
+               ONEPASS_MAX_NQ);
+  SSKD_REQUIRE(k >= 1 && k <= ONEPASS_MAX_K, "index_search_onepass: k=%d outside [1, %d]", k,
+               ONEPASS_MAX_K);
+  SSKD_REQUIRE(n_rows < ((int64_t)1 << 31) - 64, "index_search_onepass: shard too large for int32 row ids");
+  SSKD_REQUIRE(d_tiled && d_queries && d_out_scores && d_out_ids && d_inexact,
+               "index_search_onepass: null pointer");
+  const size_t need = sskd_index_search_onepass_workspace_bytes(n_rows, nq, k);
+  if (!d_workspace || workspace_bytes < need)
+    return sskd::fail(SSKD_ERR_WORKSPACE, "index_search_onepass: workspace %zu B < required %zu B",
+                      workspace_bytes, need);
+  hipStream_t st = sskd::as_stream(stream);
+  const Plan pl = onepass_plan(n_rows, nq);
+  const size_t re = onepass_reduce_elems(pl, nq, k);
+  char* ws = static_cast<char*>(d_workspace);
+  float* part_scores = reinterpret_cast<float*>(ws);
+  ws += align256(pl.part_elems * sizeof(float));
+  int* part_ids = reinterpret_cast<int*>(ws);
+  ws += align256(pl.part_elems * sizeof(int));
+  float* red_scores[2];
+  int* red_ids[2];
+  for (int i = 0; i < 2; ++i) {
+    red_scores[i] = reinterpret_cast<float*>(ws);
+    ws += align256(re * sizeof(float));
+    red_ids[i] = reinterpret_cast<int*>(ws);
+    ws += align256(re * sizeof(int));
+  }
+  float* bound_s = reinterpret_cast<float*>(ws);
+  ws += align256((size_t)nq * sizeof(float));
+  int* bound_i = reinterpret_cast<int*>(ws);
+
+  hipLaunchKernelGGL(fill_int_kernel, dim3(1), dim3(256), 0, st, d_inexact, 1, 0);
+  ScanParams sp{};
+  sp.tiled = d_tiled;
+  sp.queries = d_queries;
+  sp.part_scores = part_scores;
+  sp.part_ids = part_ids;
+  sp.ub_scores = nullptr;
+  sp.ub_ids = nullptr;
+  sp.tau = bound_i;    // unused without pools (never dereferenced), kept non-null
+  sp.gpool = bound_i;
+  sp.n_rows = n_rows;
+  sp.n_tiles = pl.n_tiles;
+  sp.nq = nq;
+  sp.n_slices = pl.n_slices;
+  sp.tiles_per_slice = pl.tiles_per_slice;
+  sp.lists_per_query = pl.lists_per_query;
+  if (pl.QB == 1) launch_scan_plain<1>(pl, sp, st);
+  else launch_scan_plain<2>(pl, sp, st);
+  int rc = sskd::check_launch("scan_topk_kernel (no pools)");
+  if (rc != SSKD_OK) return rc;
+
+  BoundParams bp{};
+  bp.scores = part_scores;
+  bp.ids = part_ids;
+  bp.k = pl.K;
+  bp.lists = pl.lists_per_query;
+  bp.nq = nq;
+  bp.bound_s = bound_s;
+  bp.bound_i = bound_i;
+  hipLaunchKernelGGL(last_entry_bound_kernel, dim3((unsigned)sskd::ceil_div(nq, 4)), dim3(256), 0, st, bp);
+  rc = sskd::check_launch("last_entry_bound_kernel");
+  if (rc != SSKD_OK) return rc;
+
+  const float* cand_scores = part_scores;
+  const int* cand_ids = part_ids;
+  int lists = pl.lists_per_query, k_in = pl.K;
+  for (int step = 0; step == 0 || lists > 1; ++step) {
+    ReduceParams rp{};
+    rp.scores = cand_scores;
+    rp.ids = cand_ids;
+    rp.k = k_in;
+    rp.k_out = k;
+    rp.lists_in = lists;
+    rp.lpg = REDUCE_MAX_CAND / k_in;
+    rp.groups = (int)sskd::ceil_div(lists, rp.lpg);
+    rp.nq = nq;
+    rp.out_scores = red_scores[step & 1];
+    rp.out_ids = red_ids[step & 1];
+    hipLaunchKernelGGL(reduce_lists_kernel, dim3((unsigned)sskd::ceil_div((int64_t)nq * rp.groups, 4)),
+                       dim3(256), 0, st, rp);
+    rc = sskd::check_launch("reduce_lists_kernel");
+    if (rc != SSKD_OK) return rc;
+    cand_scores = rp.out_scores;
+    cand_ids = rp.out_ids;
+    lists = rp.groups;
+    k_in = k;
+  }
+  FinalizeParams fp{};
+  fp.scores = cand_scores;
+  fp.ids = cand_ids;
+  fp.bound_s = bound_s;
+  fp.bound_i = bound_i;
+  fp.k = k;
+  fp.nq = nq;
+  fp.id_offset = id_offset;
+  fp.out_scores = d_out_scores;
+  fp.out_ids = d_out_ids;
+  fp.inexact = d_inexact;
+  hipLaunchKernelGGL(finalize_onepass_kernel, dim3(nq), dim3(256), 0, st, fp);
+  return sskd::check_launch("finalize_onepass_kernel");
 }
 
 int sskd_topk_merge(const float* d_scores, const int64_t* d_ids, int n_lists, int nq, int k_in,

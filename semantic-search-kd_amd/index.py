@@ -82,6 +82,7 @@ class FAISSIndexBuilder:
         self._tiled: Optional[torch.Tensor] = None  # fp32 [capacity_rows * 384], tiled layout
         self._n = 0
         self._workspace: Optional[torch.Tensor] = None
+        self.last_search_path: Optional[str] = None  # which path the last host search() took (diagnostic)
         self.index: Optional[IndexHandle] = None
 
     # ------------------------------------------------------------------ storage
@@ -264,6 +265,35 @@ class FAISSIndexBuilder:
         )
         return out_scores, out_ids
 
+    # the online shape: a handful of queries (sskd_amd.h, one-pass variant).  With a single query
+    # block the shared pruning pools of the batch kernel only cost, so the pool-free one-pass
+    # search is also the faster one for small k (where its proof cannot fail for k <= 10).
+    ONEPASS_MAX_NQ = 64
+    ONEPASS_MAX_K = 256
+
+    def _search_onepass_device(self, q: torch.Tensor, k: int, normalize_queries: bool):
+        """One corpus pass + proof of exactness; returns ``(scores, ids, inexact_flag)`` device tensors."""
+        lib = _native.load()
+        stream = _stream(self.device)
+        nq = q.shape[0]
+        if normalize_queries:
+            q = q.clone()
+            _native.check(lib.sskd_l2_normalize_rows(q.data_ptr(), nq, self.embedding_dim, stream))
+        out_scores = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+        out_ids = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        flag = torch.empty(1, dtype=torch.int32, device=self.device)
+        need = int(lib.sskd_index_search_onepass_workspace_bytes(self._n, nq, k))
+        if self._workspace is None or self._workspace.numel() < need:
+            self._workspace = torch.empty(max(need, 1), dtype=torch.uint8, device=self.device)
+        _native.check(
+            lib.sskd_index_search_onepass(
+                self._tiled.data_ptr(), self._n, q.data_ptr(), nq, k, self.id_offset,
+                out_scores.data_ptr(), out_ids.data_ptr(), flag.data_ptr(),
+                self._workspace.data_ptr(), self._workspace.numel(), stream,
+            )
+        )
+        return out_scores, out_ids, flag
+
     def _search_numpy(self, query_emb, k: int, normalize_queries: Optional[bool]) -> Tuple[np.ndarray, np.ndarray]:
         _native.require_gpu()
         q = np.ascontiguousarray(np.asarray(query_emb, dtype=np.float32))
@@ -271,6 +301,22 @@ class FAISSIndexBuilder:
             q = q[None, :]
         qd = torch.from_numpy(q).to(self.device)
         with torch.cuda.device(self.device):
+            nq = qd.shape[0]
+            if (
+                1 <= k <= self.ONEPASS_MAX_K
+                and 1 <= nq <= self.ONEPASS_MAX_NQ
+                and self._n >= 1
+                and qd.shape[1] == self.embedding_dim
+            ):
+                norm = self.metric == "cosine" if normalize_queries is None else normalize_queries
+                scores, ids, flag = self._search_onepass_device(qd, k, norm)
+                # this host path synchronises anyway (NumPy out): read the proof flag with the result
+                if int(flag.item()) == 0:
+                    self.last_search_path = "onepass"
+                    return scores.cpu().numpy(), ids.cpu().numpy()
+                self.last_search_path = "onepass-unproven+chained"
+            else:
+                self.last_search_path = "chained" if k > _native.SSKD_K_PASS else "single"
             scores, ids = self.search_device(qd, k, normalize_queries=normalize_queries)
             return scores.cpu().numpy(), ids.cpu().numpy()
 

@@ -120,6 +120,72 @@ def test_online_shapes_few_queries_many_slices(gpu, native_lib, nq, k):
     assert plan[2].value >= 64  # many slices
 
 
+def _onepass(lib, tiled, n, queries, k, id_offset=0):
+    nq = queries.shape[0]
+    q = torch.from_numpy(np.ascontiguousarray(queries, np.float32)).cuda()
+    out_s = torch.full((nq, k), float("nan"), dtype=torch.float32, device="cuda")
+    out_i = torch.full((nq, k), -7, dtype=torch.int64, device="cuda")
+    flag = torch.full((1,), 9, dtype=torch.int32, device="cuda")
+    ws = torch.empty(max(int(lib.sskd_index_search_onepass_workspace_bytes(n, nq, k)), 1), dtype=torch.uint8, device="cuda")
+    _native.check(
+        lib.sskd_index_search_onepass(
+            tiled.data_ptr(), n, q.data_ptr(), nq, k, id_offset, out_s.data_ptr(), out_i.data_ptr(),
+            flag.data_ptr(), ws.data_ptr(), ws.numel(), stream(),
+        )
+    )
+    torch.cuda.synchronize()
+    return out_s.cpu().numpy(), out_i.cpu().numpy(), int(flag.item())
+
+
+@pytest.mark.parametrize("nq,k", [(1, 33), (1, 50), (1, 100), (1, 200), (1, 256), (5, 64), (64, 100)])
+def test_onepass_large_k_is_proven_exact_on_ordinary_data(gpu, native_lib, nq, k):
+    """One corpus pass + proof (sskd_amd.h): on ordinary data the best rows are spread over the
+    per-lane lists, the proof succeeds, and the result is bit-identical to the oracle."""
+    n = 150_000
+    corpus = oracle.seeded_unit_rows(n, 384, 91)
+    queries = oracle.seeded_unit_rows(nq, 384, 92)
+    tiled = tile_corpus(native_lib, corpus)
+    s, i, inexact = _onepass(native_lib, tiled, n, queries, k, id_offset=1000)
+    assert inexact == 0
+    ref_s, ref_i = oracle.topk_fma(queries, corpus, k, 1000)
+    assert np.array_equal(i, ref_i) and np.array_equal(s, ref_s)
+
+
+def test_onepass_refuses_to_certify_when_a_list_overflows(gpu, native_lib):
+    """Sixteen near-copies of the query inside ONE per-lane list (rows 0-3, 8-11, 16-19, 24-27 of
+    one tile = one wave, one half): the list keeps ten, the proof must fail, and the host path falls
+    back to the chained search - the answer is exact either way."""
+    n = 60_000
+    corpus = oracle.seeded_unit_rows(n, 384, 93)
+    queries = oracle.seeded_unit_rows(2, 384, 94)
+    tile0 = 32 * 777
+    rows = [tile0 + (r & 3) + 8 * (r >> 2) for r in range(16)]
+    corpus[rows] = oracle.l2_normalize_rows(queries[0][None, :] + 0.02 * corpus[rows])
+    tiled = tile_corpus(native_lib, corpus)
+    _, _, inexact = _onepass(native_lib, tiled, n, queries, 50)
+    assert inexact == 1
+    # 300 rows, k = 256: every list saw 16 rows of a tile and kept ten - not certifiable either
+    small = corpus[:300]
+    _, _, inexact = _onepass(native_lib, tile_corpus(native_lib, small), 300, queries, 256)
+    assert inexact == 1
+    # 8 rows: no list is full, nothing was dropped, always proven; k beyond the row count pads
+    tiny = corpus[:8]
+    s, i, inexact = _onepass(native_lib, tile_corpus(native_lib, tiny), 8, queries, 40)
+    assert inexact == 0
+    ref_s, ref_i = oracle.topk_fma(queries, tiny, 40)
+    assert np.array_equal(i, ref_i) and np.array_equal(s, ref_s)
+    # the class falls back by itself
+    ib = FAISSIndexBuilder(384, "Flat", "ip")
+    ib.add(torch.from_numpy(corpus).cuda())
+    s, i = ib.search(queries, 50)
+    assert ib.last_search_path == "onepass-unproven+chained"
+    ref_s, ref_i = oracle.topk_fma(queries, corpus, 50)
+    assert np.array_equal(i, ref_i) and np.array_equal(s, ref_s)
+    s, i = ib.search(queries[1:], 50)
+    assert ib.last_search_path == "onepass"
+    assert np.array_equal(i, ref_i[1:]) and np.array_equal(s, ref_s[1:])
+
+
 def test_ties_resolve_to_lower_id(gpu, native_lib):
     base = oracle.seeded_unit_rows(40, 384, 5)
     corpus = np.concatenate([base, base, base[:7]])  # every row appears 2-3 times -> exact score ties
