@@ -769,21 +769,11 @@ Plan make_plan(int64_t n_rows, int nq, int k) {
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-template <int K, int QB, bool HAS_UB>
+template <int K, int QB, bool HAS_UB, bool POOLS = true>
 void launch_scan(const Plan& pl, const ScanParams& sp, hipStream_t st) {
   constexpr int WAVES = 8;
   const size_t lds = (size_t)QB * 32 * CHUNKS * sizeof(float4) + (size_t)QB * 32 * (K + 1) * sizeof(int);
-  auto kern = scan_topk_kernel<K, QB, WAVES, HAS_UB>;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kern, dim3(pl.n_qblocks * pl.n_slices), dim3(WAVES * 64), lds, st, sp);
-}
-
-template <int QB>
-void launch_scan_plain(const Plan& pl, const ScanParams& sp, hipStream_t st) {
-  constexpr int WAVES = 8, K = 10;
-  const size_t lds = (size_t)QB * 32 * CHUNKS * sizeof(float4) + (size_t)QB * 32 * (K + 1) * sizeof(int);
-  auto kern = scan_topk_kernel<K, QB, WAVES, false, false>;
+  auto kern = scan_topk_kernel<K, QB, WAVES, HAS_UB, POOLS>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kern, dim3(pl.n_qblocks * pl.n_slices), dim3(WAVES * 64), lds, st, sp);
@@ -791,7 +781,12 @@ void launch_scan_plain(const Plan& pl, const ScanParams& sp, hipStream_t st) {
 
 template <bool HAS_UB>
 int dispatch_scan(const Plan& pl, const ScanParams& sp, hipStream_t st) {
-  if (pl.K == 10 && pl.QB == 1) launch_scan<10, 1, HAS_UB>(pl, sp, st);
+  // one or two query blocks (the online shape): every workgroup sees so few tiles that the shared
+  // pruning pools cost more than they prune (1.7 -> 0.6 ms for one query over 1 M rows)
+  const bool few = pl.n_qblocks <= 2;
+  if (pl.K == 10 && pl.QB == 1 && few) launch_scan<10, 1, HAS_UB, false>(pl, sp, st);
+  else if (pl.K == 10 && pl.QB == 2 && few) launch_scan<10, 2, HAS_UB, false>(pl, sp, st);
+  else if (pl.K == 10 && pl.QB == 1) launch_scan<10, 1, HAS_UB>(pl, sp, st);
   else if (pl.K == 10 && pl.QB == 2) launch_scan<10, 2, HAS_UB>(pl, sp, st);
   else if (pl.K == 16 && pl.QB == 1) launch_scan<16, 1, HAS_UB>(pl, sp, st);
   else if (pl.K == 16 && pl.QB == 2) launch_scan<16, 2, HAS_UB>(pl, sp, st);
@@ -1070,8 +1065,8 @@ int sskd_index_search_onepass(const float* d_tiled, int64_t n_rows, const float*
   sp.n_slices = pl.n_slices;
   sp.tiles_per_slice = pl.tiles_per_slice;
   sp.lists_per_query = pl.lists_per_query;
-  if (pl.QB == 1) launch_scan_plain<1>(pl, sp, st);
-  else launch_scan_plain<2>(pl, sp, st);
+  if (pl.QB == 1) launch_scan<10, 1, false, false>(pl, sp, st);
+  else launch_scan<10, 2, false, false>(pl, sp, st);
   int rc = sskd::check_launch("scan_topk_kernel (no pools)");
   if (rc != SSKD_OK) return rc;
 
