@@ -781,9 +781,12 @@ void launch_scan(const Plan& pl, const ScanParams& sp, hipStream_t st) {
 
 template <bool HAS_UB>
 int dispatch_scan(const Plan& pl, const ScanParams& sp, hipStream_t st) {
-  // one or two query blocks (the online shape): every workgroup sees so few tiles that the shared
-  // pruning pools cost more than they prune (1.7 -> 0.6 ms for one query over 1 M rows)
-  const bool few = pl.n_qblocks <= 2;
+  // when a wave sees only a few tiles (few queries spread over many slices: the online shape), the
+  // shared pruning pools cost more than they prune: one query over 1 M rows 1.7 -> 0.33 ms without
+  // them.  Measured crossover (tools/pools_sweep.py, 1 M and 125 k rows, 64..4096 queries):
+  // 24-32 tiles per wave; the batch configurations of bench.py have 61.
+  const int pools_env = env_int("SSKD_SCAN_POOLS", -1);
+  const bool few = pools_env >= 0 ? pools_env == 0 : pl.tiles_per_slice < 24 * pl.waves;
   if (pl.K == 10 && pl.QB == 1 && few) launch_scan<10, 1, HAS_UB, false>(pl, sp, st);
   else if (pl.K == 10 && pl.QB == 2 && few) launch_scan<10, 2, HAS_UB, false>(pl, sp, st);
   else if (pl.K == 10 && pl.QB == 1) launch_scan<10, 1, HAS_UB>(pl, sp, st);
