@@ -121,6 +121,17 @@ int sskd_index_search_onepass(const float* d_tiled, int64_t n_rows, const float*
                               int* d_inexact, void* d_workspace, size_t workspace_bytes,
                               void* stream);
 
+/* Knowledge-distillation losses of the reference and their gradient (loss
+ * half).  Replaces MarginMSELoss / ListwiseKDLoss / ContrastiveLoss / CombinedKDLoss.forward
+ * (src/kd/losses.py:35-60, 81-106, 127-149, 219-252) on device-resident [batch, n_docs] fp32 score
+ * matrices, n_docs <= 64 (document 0 is the positive).  d_losses[4] = { weighted total, margin-MSE,
+ * listwise KD, contrastive }; d_grad (may be NULL) = d total / d student, [batch, n_docs];
+ * d_row_workspace = 3 * batch floats.  Single components: set the other weights to 0. */
+int sskd_kd_loss(const float* d_student, const float* d_teacher, int batch, int n_docs,
+                 float temperature, float contrastive_temperature, float w_margin_mse,
+                 float w_listwise, float w_contrastive, float* d_losses, float* d_grad,
+                 float* d_row_workspace, void* stream);
+
 /* Launch geometry the search would use (for roofline accounting in bench.py):
  * queries per workgroup tile (B_q), corpus passes, slices, waves per workgroup,
  * and scan passes needed for this k. Any out pointer may be NULL. */

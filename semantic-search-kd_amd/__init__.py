@@ -12,11 +12,16 @@ from .index import FAISSIndexBuilder, IndexHandle, read_flat_ip, write_flat_ip  
 from .weights import BertConfig, synthetic_state_dict  # noqa: F401
 from .encoder import Mi355xSentenceEncoder, build_wordpiece_tokenizer  # noqa: F401
 from .student import StudentModel  # noqa: F401
+from .losses import CombinedKDLoss, ContrastiveLoss, ListwiseKDLoss, MarginMSELoss  # noqa: F401
 from .bench_support import bench_encode, encoder_smoke_embeddings  # noqa: F401
 
 Mi355xIndexBuilder = FAISSIndexBuilder
 
 __all__ = [
+    "CombinedKDLoss",
+    "ContrastiveLoss",
+    "ListwiseKDLoss",
+    "MarginMSELoss",
     "StudentModel",
     "Mi355xSentenceEncoder",
     "FAISSIndexBuilder",

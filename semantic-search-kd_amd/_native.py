@@ -62,6 +62,7 @@ class EncoderWeights(C.Structure):
 # name -> (restype, argtypes); must list every symbol of include/sskd_amd.h
 _vp, _i, _i64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
 _ip = C.POINTER(C.c_int)
+_f = C.c_float
 SIGNATURES = {
     "sskd_abi_version": (_i, []),
     "sskd_last_error": (C.c_char_p, []),
@@ -78,6 +79,7 @@ SIGNATURES = {
     "sskd_index_search_onepass_workspace_bytes": (_sz, [_i64, _i, _i]),
     "sskd_index_search_onepass": (_i, [_vp, _i64, _vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sskd_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "sskd_kd_loss": (_i, [_vp, _vp, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "sskd_similarity": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
     "sskd_pool_normalize": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "sskd_encoder_workspace_bytes": (_sz, [C.POINTER(EncoderConfig), _i, _i]),

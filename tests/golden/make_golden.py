@@ -9,6 +9,8 @@ source files / engines are absent here, so fixtures come from:
             BASELINE cfg-1 shape (1 000 x 100, k = 10); expected outputs from the reference's exact
             search idiom (``np.matmul`` + ``argsort``: src/kd/eval.py:86, scripts/simple_eval.py:25,35)
             as restated in oracle/search.py, in BLAS order and in the kernel's fma order.
+* KD loss — the reference's own ``src/kd/losses.py`` (importable here; see ``make_kd_loss``): losses and
+            autograd gradients for the §8(f) loss row, i.e. a fixture produced by reference code.
 * encoder — ``transformers.BertModel`` (the module sentence-transformers executes for the reference's
             StudentModel) built from an in-memory ``BertConfig`` — nothing is downloaded — loaded
             with the deterministic synthetic weights of semantic-search-kd_amd/weights.py.  The
@@ -126,6 +128,63 @@ def make_bert(layers: int, tag: str):
     )
 
 
+def make_kd_loss():
+    """Losses and autograd gradients from the REFERENCE'S OWN code (src/kd/losses.py), imported from
+    /root/reference in this container only.  Its one missing dependency is a logging package used
+    for ``logger.info`` lines; an in-process no-op stand-in is registered for it (it takes no part
+    in the arithmetic).  The oracle restatement is asserted equal here."""
+    import types
+
+    from oracle import kd_losses as kd_oracle
+
+    sys.path.insert(0, "/root/reference")
+    stub = types.ModuleType("loguru")
+
+    class _Silent:
+        def __getattr__(self, name):
+            return lambda *a, **k: None
+
+    stub.logger = _Silent()
+    sys.modules.setdefault("loguru", stub)
+    from src.kd.losses import CombinedKDLoss, ContrastiveLoss, ListwiseKDLoss, MarginMSELoss
+
+    out = {}
+    cases = {"b4": (4, 9, 7), "b64": (64, 9, 8), "b5d33": (5, 33, 9), "ties": (3, 9, 10)}
+    for name, (b, d, seed) in cases.items():
+        g = torch.Generator().manual_seed(seed)
+        s = torch.randn(b, d, generator=g)
+        t = torch.randn(b, d, generator=g) * 3.0
+        if name == "ties":  # repeated row maxima: which index receives the max's gradient matters
+            s[0, 2] = s[0, 5] = s[0].max() + 0.5
+            t[1, 0] = t[1, 8] = t[1].max() + 1.0
+        out[f"{name}_s"], out[f"{name}_t"] = s.numpy(), t.numpy()
+        for temp in (4.0, 3.0, 2.0):
+            tag = f"{name}_T{int(temp)}"
+            comps = {"mm": MarginMSELoss(temp), "lk": ListwiseKDLoss(temp), "c": ContrastiveLoss(0.05)}
+            for key, fn in comps.items():
+                sv = s.clone().requires_grad_(True)
+                loss = fn(sv, t) if key != "c" else fn(sv)
+                loss.backward()
+                out[f"{tag}_{key}"] = np.float64(loss.item())
+                out[f"{tag}_{key}_grad"] = sv.grad.numpy().copy()
+            comb = CombinedKDLoss()
+            comb.update_temperature((4.0 - temp) / 2.0)  # 4 -> 2 linear annealing
+            assert abs(comb.current_temperature - temp) < 1e-12
+            sv = s.clone().requires_grad_(True)
+            res = comb(sv, t)
+            res["loss"].backward()
+            out[f"{tag}_total"] = np.float64(res["loss"].item())
+            out[f"{tag}_total_grad"] = sv.grad.numpy().copy()
+            # the restatement agrees with the reference
+            o, og = kd_oracle.combined(s.numpy(), t.numpy(), temp)
+            assert abs(o["loss"] - res["loss"].item()) < 2e-5 * max(1.0, abs(o["loss"]))
+            for key, ref in (("margin_mse", res["margin_mse"]), ("listwise_kd", res["listwise_kd"]),
+                             ("contrastive", res["contrastive"])):
+                assert abs(o[key] - ref) < 2e-5 * max(1.0, abs(ref)), (tag, key, o[key], ref)
+            assert np.abs(og - sv.grad.numpy()).max() < 2e-5 * max(1.0, np.abs(og).max()), tag
+    np.savez_compressed(HERE / "kd_loss.npz", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -134,5 +193,6 @@ if __name__ == "__main__":
     make_pool_norm()
     make_bert(2, "l2")
     make_bert(12, "l12")
+    make_kd_loss()
     for p in sorted(HERE.glob("*.npz")):
         print(f"{p.name}: {p.stat().st_size / 1024:.1f} KiB")

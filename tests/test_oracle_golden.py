@@ -98,3 +98,25 @@ def test_encoder_oracle_matches_transformers_golden(tag):
     emb = enc_oracle.mean_pool_normalize(hs[-1], gold["attention_mask"])
     np.testing.assert_allclose(emb, gold["embeddings"], atol=1e-5)
     assert float(gold["oracle_vs_hf_max_abs"]) < 2e-4
+
+
+def test_kd_loss_oracle_matches_reference_fixture():
+    """tests/golden/kd_loss.npz was produced by the reference's own src/kd/losses.py (losses and
+    autograd gradients, tests/golden/make_golden.py::make_kd_loss): the restatement is PINNED by it."""
+    from oracle import kd_losses as kd
+
+    g = np.load(GOLDEN / "kd_loss.npz")
+    for name in ("b4", "b64", "b5d33", "ties"):
+        s, t = g[f"{name}_s"], g[f"{name}_t"]
+        for temp in (4.0, 3.0, 2.0):
+            tag = f"{name}_T{int(temp)}"
+            out, grad = kd.combined(s, t, temp)
+            for key, ref_key in (("loss", "total"), ("margin_mse", "mm"), ("listwise_kd", "lk"), ("contrastive", "c")):
+                assert out[key] == pytest.approx(float(g[f"{tag}_{ref_key}"]), rel=2e-5, abs=2e-6), (tag, key)
+            np.testing.assert_allclose(grad, g[f"{tag}_total_grad"], rtol=2e-4, atol=2e-6)
+            for fn, key in ((lambda: kd.margin_mse(s, t, temp), "mm"), (lambda: kd.listwise_kd(s, t, temp), "lk"),
+                            (lambda: kd.contrastive(s), "c")):
+                loss, gr = fn()
+                assert loss == pytest.approx(float(g[f"{tag}_{key}"]), rel=2e-5, abs=2e-6)
+                np.testing.assert_allclose(gr, g[f"{tag}_{key}_grad"], rtol=2e-4, atol=2e-6)
+    assert kd.annealed_temperature(4.0, 2.0, 0.5) == 3.0
