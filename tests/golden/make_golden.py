@@ -185,6 +185,37 @@ def make_kd_loss():
     np.savez_compressed(HERE / "kd_loss.npz", **out)
 
 
+API_MODELS = ("SearchRequest", "SearchResult", "SearchResponse", "EncodeRequest", "EncodeResponse",
+              "HealthResponse", "ErrorResponse")
+
+
+def contract_of(model) -> dict:
+    """The validation-relevant part of a pydantic model's JSON schema: field names, types, defaults,
+    bounds, required fields and references - without titles, descriptions or examples."""
+    drop = {"title", "description", "example", "examples"}
+
+    def strip(node):
+        if isinstance(node, dict):
+            return {k: strip(v) for k, v in sorted(node.items()) if k not in drop}
+        if isinstance(node, list):
+            return [strip(v) for v in node]
+        return node
+
+    return strip(model.model_json_schema())
+
+
+def make_api_schemas():
+    """Request / response contract of the reference's service (src/serve/schemas.py, importable
+    here as is): the boundary the drop-in must keep."""
+    import json
+
+    sys.path.insert(0, "/root/reference")
+    from src.serve import schemas as ref
+
+    out = {name: contract_of(getattr(ref, name)) for name in API_MODELS}
+    (HERE / "api_schemas.json").write_text(json.dumps(out, indent=1, sort_keys=True) + "\n")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -194,5 +225,6 @@ if __name__ == "__main__":
     make_bert(2, "l2")
     make_bert(12, "l12")
     make_kd_loss()
+    make_api_schemas()
     for p in sorted(HERE.glob("*.npz")):
         print(f"{p.name}: {p.stat().st_size / 1024:.1f} KiB")

@@ -113,3 +113,28 @@ def test_search_glue_semantics(client):
 def test_index_load_missing_dir_is_404(client):
     r = client.post("/index/load", params={"index_path": "/nonexistent/dir"})
     assert r.status_code == 404 and "Index not found" in r.json()["error"]
+
+
+def test_request_response_contract_matches_the_reference_schemas():
+    """tests/golden/api_schemas.json is the validation contract (field names, types, defaults, bounds,
+    required fields) extracted from the reference's own src/serve/schemas.py by
+    tests/golden/make_golden.py::make_api_schemas; the drop-in's models must state the same."""
+    import json
+    from pathlib import Path
+
+    from semantic_search_kd_amd.serve import schemas as mine
+
+    ref = json.loads((Path(__file__).resolve().parent / "golden" / "api_schemas.json").read_text())
+    drop = {"title", "description", "example", "examples"}
+
+    def strip(node):
+        if isinstance(node, dict):
+            return {k: strip(v) for k, v in sorted(node.items()) if k not in drop}
+        if isinstance(node, list):
+            return [strip(v) for v in node]
+        return node
+
+    assert set(ref) == {"SearchRequest", "SearchResult", "SearchResponse", "EncodeRequest", "EncodeResponse",
+                        "HealthResponse", "ErrorResponse"}
+    for name, contract in ref.items():
+        assert strip(getattr(mine, name).model_json_schema()) == contract, name
