@@ -1,7 +1,7 @@
 // Knowledge-distillation losses of the reference (src/kd/losses.py) and their gradient with respect
 // to the student scores, for [B, D] score matrices (D <= 64: the reference trains on D = 9, one
 // positive + hard negatives per query).  One wave per row keeps a row in registers (lane = document);
-// a second, single-wave kernel adds the per-row terms in a fixed order, so results are
+// a second, single-workgroup kernel adds the per-row terms in a fixed order, so results are
 // bit-reproducible.  All arithmetic is fp32, like the reference's torch code.
 //
 //   margin-MSE   :35-60    mean_{b,j} ( (s - max_j s) - (t/T - max_j t/T) )^2
@@ -92,10 +92,11 @@ __global__ __launch_bounds__(256) void kd_loss_rows_kernel(KdParams p) {
   }
 }
 
-__global__ __launch_bounds__(64) void kd_loss_finish_kernel(KdParams p) {
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(1024) void kd_loss_finish_kernel(KdParams p) {
+  __shared__ float part[16][3];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-  for (int r = lane; r < p.B; r += 64) {  // fixed order: reproducible
+  for (int r = tid; r < p.B; r += 1024) {  // fixed strides and a fixed tree: reproducible
     a0 += p.rows[r * 3 + 0];
     a1 += p.rows[r * 3 + 1];
     a2 += p.rows[r * 3 + 2];
@@ -104,9 +105,21 @@ __global__ __launch_bounds__(64) void kd_loss_finish_kernel(KdParams p) {
   a1 = wave_sum(a1);
   a2 = wave_sum(a2);
   if (lane == 0) {
-    const float mm = a0 / ((float)p.B * (float)p.D);
-    const float lk = a1 / (float)p.B * (p.T * p.T);
-    const float c = a2 / (float)p.B;
+    part[wave][0] = a0;
+    part[wave][1] = a1;
+    part[wave][2] = a2;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int w = 0; w < 16; ++w) {
+      s0 += part[w][0];
+      s1 += part[w][1];
+      s2 += part[w][2];
+    }
+    const float mm = s0 / ((float)p.B * (float)p.D);
+    const float lk = s1 / (float)p.B * (p.T * p.T);
+    const float c = s2 / (float)p.B;
     p.losses[0] = p.w_mm * mm + p.w_lk * lk + p.w_c * c;
     p.losses[1] = mm;
     p.losses[2] = lk;
@@ -141,6 +154,6 @@ extern "C" int sskd_kd_loss(const float* d_student, const float* d_teacher, int 
   hipLaunchKernelGGL(kd_loss_rows_kernel, dim3((unsigned)sskd::ceil_div(batch, 4)), dim3(256), 0, st, p);
   int rc = sskd::check_launch("kd_loss_rows_kernel");
   if (rc != SSKD_OK) return rc;
-  hipLaunchKernelGGL(kd_loss_finish_kernel, dim3(1), dim3(64), 0, st, p);
+  hipLaunchKernelGGL(kd_loss_finish_kernel, dim3(1), dim3(1024), 0, st, p);
   return sskd::check_launch("kd_loss_finish_kernel");
 }
