@@ -186,6 +186,30 @@ def test_onepass_refuses_to_certify_when_a_list_overflows(gpu, native_lib):
     assert np.array_equal(i, ref_i[1:]) and np.array_equal(s, ref_s[1:])
 
 
+def test_host_search_randomised_small_shapes_with_ties(gpu):
+    """FAISSIndexBuilder.search() (one pass + proof, chained fallback) on 40 random shapes: row counts
+    around tile boundaries, 1-64 queries, k up to 256 and beyond the row count, corpora made largely
+    of duplicated rows (exact score ties) - always bit-identical to the oracle, whichever path ran."""
+    rng = np.random.default_rng(2024)
+    paths = set()
+    for case in range(40):
+        n = int(rng.choice([1, 7, 31, 32, 33, 100, 257, 1000, 4096, 5000]))
+        nq = int(rng.choice([1, 2, 5, 32, 33, 64]))
+        k = int(rng.choice([1, 5, 10, 11, 32, 33, 64, 100, 200, 256]))
+        base = oracle.seeded_unit_rows(max(n // 3, 1), 384, 1000 + case)
+        corpus = base[rng.integers(0, base.shape[0], size=n)]          # ~3 copies of every row
+        queries = oracle.seeded_unit_rows(nq, 384, 2000 + case)
+        queries[0] = corpus[rng.integers(0, n)]                         # an exact hit with its copies
+        ib = FAISSIndexBuilder(384, "Flat", "ip")
+        ib.add(torch.from_numpy(np.ascontiguousarray(corpus)).cuda())
+        s, i = ib.search(queries, k)
+        ref_s, ref_i = oracle.topk_fma(queries, corpus, k)
+        assert np.array_equal(i, ref_i), (case, n, nq, k, ib.last_search_path)
+        assert np.array_equal(s, ref_s), (case, n, nq, k, ib.last_search_path)
+        paths.add(ib.last_search_path)
+    assert "onepass" in paths
+
+
 def test_ties_resolve_to_lower_id(gpu, native_lib):
     base = oracle.seeded_unit_rows(40, 384, 5)
     corpus = np.concatenate([base, base, base[:7]])  # every row appears 2-3 times -> exact score ties
