@@ -62,11 +62,14 @@ class Mi355xSentenceEncoder:
     # ----------------------------------------------------------- constructors
     @classmethod
     def from_synthetic(
-        cls, config: Optional[BertConfig] = None, device: Optional[str] = None, tokenizer=None, **kw
+        cls, config: Optional[BertConfig] = None, device: Optional[str] = None, tokenizer=None,
+        stress: bool = False, **kw
     ) -> "Mi355xSentenceEncoder":
-        """Random-init weights of the e5-small-v2 architecture (deterministic recipe, weights.py)."""
+        """Random-init weights of the e5-small-v2 architecture (deterministic recipe, weights.py);
+        ``stress`` = the trained-checkpoint-like hard-case recipe (peaky attention, outlier channels)."""
         cfg = config or BertConfig()
-        return cls(None, device, config=cfg, state_dict=synthetic_state_dict(cfg), tokenizer=tokenizer, **kw)
+        sd = synthetic_state_dict(cfg, stress=stress)
+        return cls(None, device, config=cfg, state_dict=sd, tokenizer=tokenizer, **kw)
 
     # ------------------------------------------------------ SentenceTransformer API
     def get_sentence_embedding_dimension(self) -> int:

@@ -67,21 +67,41 @@ def synthetic_tensor(name: str, shape, scale: float) -> np.ndarray:
     return ((2.0 * u - 1.0) * scale).astype(np.float32).reshape(shape)
 
 
-def synthetic_state_dict(cfg: BertConfig, nonzero_bias: bool = True) -> Dict[str, np.ndarray]:
+STRESS_OUTLIER_CHANNELS = (7, 133, 300)
+
+
+def synthetic_state_dict(cfg: BertConfig, nonzero_bias: bool = True, stress: bool = False) -> Dict[str, np.ndarray]:
     """fp32 state dict with HF ``BertModel`` parameter names (no pooler: mean pooling ignores it).
 
     ``nonzero_bias`` also draws biases / LayerNorm parameters (small, around their defaults) so
     that parity tests exercise every term of the forward pass.
+
+    ``stress`` draws weights shaped like a TRAINED checkpoint's hard cases instead of the benign
+    init: query / key projections scaled up so that attention logits are O(5) (peaky softmax rows:
+    the online-softmax rescale and bf16 P.V paths matter), LayerNorm gains log-uniform in
+    [0.3, 3], biases of +-0.5, and three outlier channels whose LayerNorm bias is +-10 (the
+    near-constant massive-activation channels real BERT checkpoints have: 10x the typical value).
     """
     h, f = cfg.hidden_size, cfg.intermediate_size
     w_scale = 0.02 * np.sqrt(3.0)
 
     def mat(name, shape):
-        return synthetic_tensor(name, shape, w_scale)
+        w = synthetic_tensor(name, shape, w_scale)
+        if stress and (".query." in name or ".key." in name):
+            w = w * np.float32(3.5)
+        return w
 
     def vec(name, n, centre):
         if not nonzero_bias:
             return np.full(n, centre, np.float32)
+        if stress:
+            u = synthetic_tensor(name, (n,), 1.0)
+            if centre == 1.0:  # LayerNorm gain
+                return np.power(np.float32(3.0), u).astype(np.float32)
+            b = (0.5 * u).astype(np.float32)
+            if "LayerNorm" in name:  # near-constant massive activations in a few channels
+                b[list(STRESS_OUTLIER_CHANNELS)] = np.float32(10.0) * np.sign(b[list(STRESS_OUTLIER_CHANNELS)])
+            return b
         return (centre + synthetic_tensor(name, (n,), 0.1)).astype(np.float32)
 
     sd = {

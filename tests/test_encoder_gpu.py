@@ -76,6 +76,48 @@ def test_encoder_matches_transformers_golden(gpu, tag):
     assert _cos(cls, gold["last_hidden_cls"]).min() >= COS_MIN
 
 
+@pytest.mark.parametrize("tag", ["stress_l2", "stress_l12"])
+def test_encoder_stress_weights_match_transformers_golden(gpu, tag):
+    """Hard-case weights (weights.synthetic_state_dict(stress=True): attention logits O(5) so
+    softmax rows are peaky and the online-softmax rescale fires, LayerNorm gains in [0.3, 3],
+    +-10 massive-activation channels), sequences of up to 7 key tiles; golden =
+    transformers.BertModel fp32 (tests/golden/make_golden.py).  Same gate as the benign weights."""
+    gold = np.load(GOLDEN / f"bert_{tag}.npz")
+    cfg = BertConfig(num_hidden_layers=int(gold["layers"]))
+    enc = Mi355xSentenceEncoder.from_synthetic(cfg, device="cuda:0", stress=True)
+    emb = enc.encode_token_ids(gold["input_ids"], gold["attention_mask"]).cpu().numpy()
+    np.testing.assert_allclose(np.linalg.norm(emb, axis=1), 1.0, atol=1e-5)
+    cos = _cos(emb, gold["embeddings"])
+    assert cos.min() >= COS_MIN, cos
+    assert np.abs(emb - gold["embeddings"]).max() <= EMB_ATOL
+    hs = enc.hidden_states(gold["input_ids"], gold["attention_mask"]).float().cpu().numpy()
+    assert _cos(hs[:, 0, :], gold["last_hidden_cls"]).min() >= COS_MIN
+
+
+@pytest.mark.parametrize("stress", [False, True])
+def test_encoder_cfg2_shape_sampled_rows_vs_oracle(gpu, stress):
+    """BASELINE cfg 2 encoder shape (batch 512 x seq 256, 12 layers) on the GPU; 8 sampled rows are
+    compared with the fp32 oracle run on those rows alone (valid because an embedding does not
+    depend on its batch-mates: test_padding_invariance)."""
+    cfg = BertConfig()
+    enc = Mi355xSentenceEncoder.from_synthetic(cfg, device="cuda:0", stress=stress)
+    sd = synthetic_state_dict(cfg, stress=stress)
+    B, S = 512, 256
+    rng = np.random.default_rng(77)
+    lengths = [S] * B
+    for b in (5, 100, 257, 511):      # a few ragged rows inside the otherwise full-length batch
+        lengths[b] = int(rng.integers(3, S))
+    ids, mask = enc_oracle.synthetic_token_ids(B, S, seed=2024, lengths=lengths)
+    emb = enc.encode_token_ids(ids, mask).cpu().numpy()
+    assert emb.shape == (B, 384) and np.isfinite(emb).all()
+    np.testing.assert_allclose(np.linalg.norm(emb, axis=1), 1.0, atol=1e-5)
+    rows = np.array([0, 5, 100, 255, 256, 257, 300, 511])
+    want = enc_oracle.encode_token_ids(sd, ids[rows], mask[rows], cfg.num_hidden_layers)
+    cos = _cos(emb[rows], want)
+    assert cos.min() >= COS_MIN, cos
+    assert np.abs(emb[rows] - want).max() <= EMB_ATOL
+
+
 def test_hidden_states_vs_oracle_same_weights(enc_l2):
     """Per-token hidden states vs the fp32 oracle run on the SAME bf16-rounded weights: isolates
     kernel arithmetic (bf16 activations) from weight quantisation."""

@@ -46,6 +46,35 @@ def test_search_1k_cfg1_shape():
     np.testing.assert_allclose(ts.numpy(), gold["blas_scores"], atol=1e-6)
 
 
+def _ref_inputs(tag, gold):
+    if tag == "small":
+        return gold["queries"], gold["corpus"], (1, 3, 10, 20)
+    return oracle.seeded_unit_rows(100, 384, 4321), oracle.seeded_unit_rows(1000, 384, 1234), (1, 5, 10)
+
+
+@pytest.mark.parametrize("tag", ["small", "1k"])
+def test_oracle_pinned_by_reference_search_code(tag):
+    """tests/golden/search_ref_*.npz hold what the REFERENCE'S OWN code computed
+    (scripts/simple_eval.py:16-49 evaluate_model and src/kd/eval.py:65-99, driven by
+    make_golden.make_search_ref): the ids its np.argsort(...)[::-1][:k] selected and the scores
+    its np.matmul produced.  Both oracle restatements must reproduce them."""
+    gold = np.load(GOLDEN / f"search_ref_{tag}.npz")
+    q, c, ks = _ref_inputs(tag, gold)
+    near = set(gold["near_tie_queries"].tolist())
+    firm = np.array([i for i in range(q.shape[0]) if i not in near])
+    for k in ks:
+        ref_i, ref_s = gold[f"ref_ids_k{k}"], gold[f"ref_scores_k{k}"]
+        kk = ref_i.shape[1]                      # the reference returns min(k, N) ids, no padding
+        for fn in (oracle.topk_blas, oracle.topk_fma):
+            s, i = fn(q, c, k)
+            assert np.array_equal(i[firm, :kk], ref_i[firm]), (tag, k, fn.__name__)
+            np.testing.assert_allclose(s[:, :kk], ref_s, atol=1e-6)
+            assert (i[:, kk:] == -1).all()       # faiss-style padding beyond N (tests/conftest.py:184-185)
+        # the reference's own mrr@k follows from the recorded ids (src/utils/metrics.py:40-55)
+        rr = [(1.0 / (list(r).index(rel) + 1)) if rel in r else 0.0 for r, rel in zip(ref_i, gold["relevant"])]
+        assert abs(np.mean(rr) - float(gold[f"ref_mrr_k{k}"])) < 1e-12
+
+
 def test_topk_semantics_ties_padding_nan():
     s = np.array([[0.5, 0.9, 0.9, np.nan, 0.1, -np.inf]], np.float32)
     ts, ti = oracle.topk_of_scores(s, 5)

@@ -63,6 +63,31 @@ def test_conftest_recipe_10_docs(gpu, native_lib):
             assert (s[:, 10:] == np.finfo(np.float32).min).all()
 
 
+@pytest.mark.parametrize("tag", ["small", "1k"])
+def test_hip_search_matches_reference_code_fixture(gpu, native_lib, tag):
+    """HIP scan vs ids / scores produced by the reference's own evaluate_model / KDEvaluator
+    (tests/golden/search_ref_*.npz, see make_golden.make_search_ref): identical ids, scores
+    within the north-star tolerance (observed ~1e-7)."""
+    from conftest import GOLDEN
+
+    gold = np.load(GOLDEN / f"search_ref_{tag}.npz")
+    if tag == "small":
+        q, c, ks = gold["queries"], gold["corpus"], (1, 3, 10, 20)
+    else:
+        q, c, ks = oracle.seeded_unit_rows(100, 384, 4321), oracle.seeded_unit_rows(1000, 384, 1234), (1, 5, 10)
+    near = set(gold["near_tie_queries"].tolist())
+    firm = np.array([i for i in range(q.shape[0]) if i not in near])
+    tiled = tile_corpus(native_lib, c)
+    for k in ks:
+        s, i = capi_search(native_lib, tiled, c.shape[0], q, k)
+        ref_i, ref_s = gold[f"ref_ids_k{k}"], gold[f"ref_scores_k{k}"]
+        kk = ref_i.shape[1]
+        assert np.array_equal(i[firm, :kk], ref_i[firm])
+        assert np.abs(s[:, :kk] - ref_s).max() <= SCORE_TOL
+        assert np.abs(s[:, :kk] - ref_s).max() <= 1e-6
+        assert (i[:, kk:] == -1).all()
+
+
 @pytest.mark.parametrize(
     "n,nq,k",
     [
