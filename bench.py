@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Headline benchmark: queries/s @ top-10 over a 1M x 384-d corpus (+ docs embedded/s).
 
-Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` (N > 1 is launched by
-``python -m torch.distributed.run``, one rank per GPU over RCCL) prints ONE JSON line on rank 0.
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line on rank 0.
+For N > 1 the driver launches it under ``python -m torch.distributed.run`` (one rank per GPU over
+RCCL); started from a bare shell without ``RANK`` in the environment it starts that launcher itself
+as a CHILD process - before anything touches the GPU - and exits with the child's return code.
 
 Workload = BASELINE.json configs[1]:
   search : corpus 1 000 000 x 384 fp32 unit rows (seed 1234) resident in HBM, row-sharded over
@@ -87,6 +89,93 @@ def cpu_search_baseline(corpus_host: np.ndarray, queries_host: np.ndarray, k: in
     return done / dt, done, dt
 
 
+def cpu_encode_baseline(batch: int = 32, seq_len: int = 256, max_docs: int = 1000, budget_s: float = 15.0):
+    """The reference's encode path on the box's host cores: ``transformers.BertModel`` (what
+    sentence-transformers executes for StudentModel.encode) + mean-pool + L2-normalise, fp32, batch 32
+    (the reference CLI default, scripts/build_faiss_index.py:20), same synthetic weights and token
+    shape as the GPU leg; bounded sample (~budget_s).  Without ``transformers`` on the box the
+    repo's torch-CPU restatement (oracle/encoder.py) is timed instead (kind "port")."""
+    import importlib.util
+
+    from oracle import encoder as enc_oracle  # checker / baseline leg only
+    from semantic_search_kd_amd.weights import BertConfig, synthetic_state_dict
+
+    cfg = BertConfig()
+    sd = synthetic_state_dict(cfg)
+    ids, mask = enc_oracle.synthetic_token_ids(batch, seq_len, seed=0)
+    engine = "oracle/encoder.py torch-CPU restatement"
+    model = None
+    if importlib.util.find_spec("transformers") is not None:
+        try:
+            from transformers import BertConfig as HFConfig
+            from transformers import BertModel
+
+            hf_cfg = HFConfig(
+                vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                max_position_embeddings=cfg.max_position_embeddings, type_vocab_size=cfg.type_vocab_size,
+                layer_norm_eps=cfg.layer_norm_eps, hidden_act="gelu", hidden_dropout_prob=0.0,
+                attention_probs_dropout_prob=0.0,
+            )
+            model = BertModel(hf_cfg, add_pooling_layer=False).eval()
+            model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+            engine = "transformers.BertModel"
+        except Exception:
+            model = None
+    tid, tmask = torch.from_numpy(ids).long(), torch.from_numpy(mask).long()
+
+    def one_batch():
+        if model is not None:
+            with torch.no_grad():
+                h = model(input_ids=tid, attention_mask=tmask).last_hidden_state.numpy()
+            return enc_oracle.mean_pool_normalize(h, mask, True)
+        return enc_oracle.encode_token_ids(sd, ids, mask, cfg.num_hidden_layers)
+
+    one_batch()  # warm-up (thread pools, allocator)
+    done, t0 = 0, time.perf_counter()
+    while done < max_docs:
+        e = one_batch()
+        done += batch
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    assert np.isfinite(e).all()
+    return {
+        "value": round(done / dt, 2),
+        "unit": "docs/s",
+        "cores": torch.get_num_threads(),
+        "kind": "reference" if model is not None else "port",
+        "sample": f"{done} passages of {seq_len} tokens in batches of {batch} ({engine}, fp32, the GPU leg's "
+                  f"synthetic weights), {dt:.1f} s",
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def faiss_probe() -> str:
+    """the reference's HNSW path is timed only when faiss is importable on the box."""
+    import importlib.util
+
+    return "available" if importlib.util.find_spec("faiss") is not None else \
+        "faiss not installed on this box: the reference's IndexHNSWFlat path cannot be timed; " \
+        "cpu_baseline is the exact IndexFlatIP idiom (numpy sgemm + top-k)"
+
+
+def self_launch(args) -> int:
+    """``bench.py --gpus N`` from a bare shell: start the torch.distributed launcher as a child
+    (never exec: this process must not have touched the GPU, and it has not) and return its code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,11 +186,31 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encode", action="store_true")
     ap.add_argument("--no-ragged", action="store_true", help="skip the ragged-length encode leg")
+    ap.add_argument("--no-text", action="store_true", help="skip the text -> embedding leg")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous + one all-gather over gloo on CPU, no GPU work: tests the N > 1 launch plumbing")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))  # nothing above this line touches the GPU
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.launch_check:
+        import torch.distributed as dist
+
+        assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+            got = torch.empty(world, dtype=torch.int64)
+            dist.all_gather_into_tensor(got, torch.tensor([rank], dtype=torch.int64))
+            assert got.tolist() == list(range(world))
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "ranks": world}), flush=True)
+        return
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -147,7 +256,10 @@ def main() -> None:
     index = pkg.FAISSIndexBuilder(embedding_dim=DIM, index_type="HNSW", metric="ip", device=str(dev), id_offset=lo)
     index.add(shard)
     n_local = index.ntotal
-    searcher = ShardedSearcher(lambda q, k: index.search_device(q, k, normalize_queries=False))
+    def local_search(q, k, out_scores=None, out_ids=None):
+        return index.search_device(q, k, normalize_queries=False, out_scores=out_scores, out_ids=out_ids)
+
+    searcher = ShardedSearcher(local_search)
 
     # profiled variant of the local scan (events around the scan kernel, same stream)
     ev = HipEvents()
@@ -157,16 +269,18 @@ def main() -> None:
     out_i = torch.empty((nq, K), dtype=torch.int64, device=dev)
     ev_pairs = [(ev.create(), ev.create()) for _ in range(args.steps)]
 
-    def local_search_profiled(step):
+    def local_search_profiled(step, out_scores=None, out_ids=None):
         a, b = ev_pairs[step]
+        o_s = out_s if out_scores is None else out_scores
+        o_i = out_i if out_ids is None else out_ids
         _native.check(
             lib.sskd_index_search_profiled(
                 index._tiled.data_ptr(), n_local, queries.data_ptr(), nq, K, lo,
-                out_s.data_ptr(), out_i.data_ptr(), ws.data_ptr(), ws.numel(),
+                o_s.data_ptr(), o_i.data_ptr(), ws.data_ptr(), ws.numel(),
                 int(torch.cuda.current_stream(dev).cuda_stream), a, b,
             )
         )
-        return out_s, out_i
+        return o_s, o_i
 
     def barrier():
         torch.cuda.synchronize()
@@ -179,7 +293,8 @@ def main() -> None:
     barrier()
     t0 = time.perf_counter()
     for step in range(args.steps):
-        searcher.local_search = lambda q, k, _s=step: local_search_profiled(_s)
+        searcher.local_search = (lambda q, k, out_scores=None, out_ids=None, _s=step:
+                                 local_search_profiled(_s, out_scores, out_ids))
         res = searcher.search(queries, K)
     barrier()
     dt = time.perf_counter() - t0
@@ -197,11 +312,14 @@ def main() -> None:
     alg_bytes = passes.value * n_local * DIM * 4 + nq * DIM * 4 + nq * K * 12
     achieved_gbs = alg_bytes / (scan_ms * 1e-3) / 1e9
     flops = 2.0 * nq * n_local * DIM
-    traffic = None
+    # HBM bytes per launch from the PMC counters: they cannot be read from inside this process, so the
+    # number comes from the committed rocprofv3 --pmc passes of this same command and says so
+    traffic, traffic_from = None, None
     tpath = REPO / "profiles" / "scan_traffic.json"
     if tpath.exists() and world == 1 and n == N_CORPUS and nq == N_QUERIES:
         try:
-            traffic = json.loads(tpath.read_text()).get("hbm_bytes_per_launch")
+            tj = json.loads(tpath.read_text())
+            traffic, traffic_from = tj.get("hbm_bytes_per_launch"), tj.get("from")
         except Exception:
             traffic = None
 
@@ -210,6 +328,7 @@ def main() -> None:
         "value": round(qps, 1),
         "unit": "queries/s",
         "n_gpus": world,
+        "rccl_ranks": dist.get_world_size() if world > 1 else 1,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
@@ -240,6 +359,7 @@ def main() -> None:
             "unit": "TFLOP/s",
             "frac": round(flops / (scan_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
             "traffic": traffic,
+            "traffic_from": traffic_from,
             "kernel_ms": round(scan_ms, 4),
             "algorithmic_flops": flops,
             "hbm_algorithmic_bytes": alg_bytes,
@@ -257,7 +377,10 @@ def main() -> None:
             bench_encode = None
         if bench_encode is not None:
             line["encode"] = bench_encode(dev, world, args.steps, args.warmup, barrier,
-                                          ragged=not args.no_ragged and rank == 0)
+                                          ragged=not args.no_ragged and rank == 0,
+                                          text=not args.no_text and rank == 0)
+            if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                line["encode"]["cpu_baseline"] = cpu_encode_baseline()
 
     # ---- CPU baseline: rank 0, N = 1 only --------------------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -280,6 +403,7 @@ def main() -> None:
             "sample": f"{cpu_nq} of the {nq} queries against the full {n}-row corpus "
             f"(numpy sgemm + argpartition, the reference's exact-search idiom), {cpu_dt:.1f} s",
             "host_cpus": os.cpu_count(),
+            "faiss_hnsw": faiss_probe(),
         }
         # parity spot check of what was just measured (first 100 queries, vs the same idiom)
         from oracle import search as oracle

@@ -97,6 +97,25 @@ int sskd_index_search(const float* d_tiled, int64_t n_rows,
                       float* d_out_scores, int64_t* d_out_ids,
                       void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* Explicit launch tuning (all zero / NULL = the built-in plan).  The SAME struct must be passed
+ * to sskd_index_search_workspace_bytes_ex, sskd_index_search_plan_ex and sskd_index_search_ex:
+ * the workspace size depends on it, and there is no process-global (environment) state behind
+ * these calls. */
+typedef struct sskd_search_tuning {
+  int32_t queries_per_block;  /* 0 = auto, else 32 or 64 (B_q of the scan kernel) */
+  int32_t target_workgroups;  /* 0 = auto, else the number of workgroups the slicing aims for */
+  int32_t pruning_pools;      /* 0 = auto, > 0 force the shared candidate pools on, < 0 off */
+} sskd_search_tuning;
+
+size_t sskd_index_search_workspace_bytes_ex(int64_t n_rows, int nq, int k,
+                                            const sskd_search_tuning* tuning);
+/* sskd_index_search with the tuning struct and two optional hipEvent_t handles (as void*, may be
+ * NULL) recorded on `stream` immediately before / after the first scan kernel. */
+int sskd_index_search_ex(const float* d_tiled, int64_t n_rows, const float* d_queries, int nq,
+                         int k, int64_t id_offset, float* d_out_scores, int64_t* d_out_ids,
+                         void* d_workspace, size_t workspace_bytes, void* stream,
+                         const sskd_search_tuning* tuning, void* ev_scan_begin, void* ev_scan_end);
+
 /* sskd_index_search with two optional hipEvent_t handles (as void*, may be NULL)
  * recorded on `stream` immediately before and after the first scan kernel: lets a
  * caller time the dominant kernel in-process (bench.py's roofline). */
@@ -139,6 +158,10 @@ int sskd_index_search_plan(int64_t n_rows, int nq, int k, int* queries_per_block
                            int* corpus_passes, int* n_slices, int* waves_per_block,
                            int* scan_passes);
 
+int sskd_index_search_plan_ex(int64_t n_rows, int nq, int k, const sskd_search_tuning* tuning,
+                              int* queries_per_block, int* corpus_passes, int* n_slices,
+                              int* waves_per_block, int* scan_passes);
+
 /* Merge `n_lists` per-shard top-k lists per query into one (the step after the
  * RCCL all-gather; the reference has a single index, so no counterpart).
  * d_scores fp32 [n_lists, nq, k_in], d_ids int64 [n_lists, nq, k_in] (global ids,
@@ -146,6 +169,14 @@ int sskd_index_search_plan(int64_t n_rows, int nq, int k, int* queries_per_block
 int sskd_topk_merge(const float* d_scores, const int64_t* d_ids, int n_lists, int nq,
                     int k_in, int k_out, float* d_out_scores, int64_t* d_out_ids,
                     void* stream);
+
+/* The same merge over PACKED per-shard records, the form one RCCL all-gather moves: record r
+ * (r = 0 .. n_lists-1) starts at d_records + r * sskd_topk_record_bytes(nq, k_in) and holds
+ * { int64 ids[nq][k_in]; float scores[nq][k_in]; padding to 16 B }.  A rank lets its local search
+ * write ids / scores straight into its own record, all-gathers the records once, and merges. */
+size_t sskd_topk_record_bytes(int nq, int k);
+int sskd_topk_merge_packed(const void* d_records, int n_lists, int nq, int k_in, int k_out,
+                           float* d_out_scores, int64_t* d_out_ids, void* stream);
 
 /* q @ d^T in fp32: replaces StudentModel.compute_similarity
  *   reference: src/kd/eval.py:75, tests/test_student_model.py:104-124 */

@@ -59,6 +59,12 @@ class EncoderWeights(C.Structure):
     ]
 
 
+class SearchTuning(C.Structure):
+    """``sskd_search_tuning``: explicit launch tuning, passed to the workspace query AND the search."""
+
+    _fields_ = [("queries_per_block", C.c_int32), ("target_workgroups", C.c_int32), ("pruning_pools", C.c_int32)]
+
+
 # name -> (restype, argtypes); must list every symbol of include/sskd_amd.h
 _vp, _i, _i64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
 _ip = C.POINTER(C.c_int)
@@ -76,6 +82,13 @@ SIGNATURES = {
     "sskd_index_search": (_i, [_vp, _i64, _vp, _i, _i, _i64, _vp, _vp, _vp, _sz, _vp]),
     "sskd_index_search_profiled": (_i, [_vp, _i64, _vp, _i, _i, _i64, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     "sskd_index_search_plan": (_i, [_i64, _i, _i, _ip, _ip, _ip, _ip, _ip]),
+    "sskd_index_search_workspace_bytes_ex": (_sz, [_i64, _i, _i, C.POINTER(SearchTuning)]),
+    "sskd_index_search_ex": (
+        _i, [_vp, _i64, _vp, _i, _i, _i64, _vp, _vp, _vp, _sz, _vp, C.POINTER(SearchTuning), _vp, _vp]
+    ),
+    "sskd_index_search_plan_ex": (_i, [_i64, _i, _i, C.POINTER(SearchTuning), _ip, _ip, _ip, _ip, _ip]),
+    "sskd_topk_record_bytes": (_sz, [_i, _i]),
+    "sskd_topk_merge_packed": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "sskd_index_search_onepass_workspace_bytes": (_sz, [_i64, _i, _i]),
     "sskd_index_search_onepass": (_i, [_vp, _i64, _vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sskd_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),

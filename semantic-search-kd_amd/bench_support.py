@@ -29,7 +29,7 @@ def synthetic_ids(batch: int, seq_len: int, vocab: int, device, seed: int = 0):
 
 
 def bench_encode(device, world: int, steps: int, warmup: int, barrier, batch: int = 512, seq_len: int = 256,
-                 ragged: bool = True):
+                 ragged: bool = True, text: bool = False):
     """docs embedded / s: every rank encodes its own ``batch x seq_len`` synthetic batches
     (pure data parallel, no communication); whole-job rate = world * batch * steps / max-rank time."""
     import torch.distributed as dist

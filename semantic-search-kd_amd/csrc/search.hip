@@ -430,8 +430,9 @@ template <typename IdT>
 struct MergeParams {
   const float* scores;
   const IdT* ids;
-  int64_t list_stride;  // elements between consecutive lists of one query
-  int64_t q_stride;     // elements between consecutive queries
+  int64_t list_stride;     // score elements between consecutive lists of one query
+  int64_t id_list_stride;  // id elements between consecutive lists of one query
+  int64_t q_stride;        // elements between consecutive queries
   int k_in;             // entries per list
   int n_cand;           // n_lists * k_in
   int nq;
@@ -463,10 +464,9 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(MergeParams<IdT> p) {
     long long best_i = -1;
     for (int c = lane; c < p.n_cand; c += 64) {
       const int l = c / p.k_in, e = c - l * p.k_in;
-      const int64_t off = (int64_t)l * p.list_stride + e;
-      const long long ci = (long long)id[off];
+      const long long ci = (long long)id[(int64_t)l * p.id_list_stride + e];
       if (ci < 0) continue;
-      const float cs = sc[off];
+      const float cs = sc[(int64_t)l * p.list_stride + e];
       // strictly after the bound in rank order
       if (have_bound && !(cs < bs || (cs == bs && ci > bi))) continue;
       if (best_i < 0 || cs > best_s || (cs == best_s && ci < best_i)) { best_s = cs; best_i = ci; }
@@ -717,17 +717,15 @@ struct Plan {
   int n_tiles;
   int lists_per_query;
   int passes;     // scan passes of K results each (k > K is served by chaining)
+  bool pools;     // shared pruning pools on (batch shapes) or off (few tiles per wave)
   size_t part_elems;
   int reduce_lpg;       // lists per group of a reduce step
   size_t reduce_elems;  // elements of one reduce buffer (0: no reduce step needed); two are kept
 };
 
-int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
-}
-
-Plan make_plan(int64_t n_rows, int nq, int k) {
+// Tuning is an explicit argument (sskd_search_tuning) that the caller hands to BOTH the workspace
+// query and the search: there is no process-global state behind the hot call.
+Plan make_plan(int64_t n_rows, int nq, int k, const sskd_search_tuning* tn = nullptr) {
   Plan pl{};
   pl.n_tiles = (int)sskd::ceil_div(n_rows, TILE_ROWS);
   const int kk = k < SSKD_K_PASS ? k : SSKD_K_PASS;
@@ -740,8 +738,7 @@ Plan make_plan(int64_t n_rows, int nq, int k) {
   pl.passes = (int)sskd::ceil_div(k, pl.K);
   pl.waves = 8;
   int qb = nq > 32 ? 2 : 1;
-  const int qb_env = env_int("SSKD_SCAN_QB", 0);
-  if (qb_env == 1 || qb_env == 2) qb = qb_env;
+  if (tn && (tn->queries_per_block == 32 || tn->queries_per_block == 64)) qb = tn->queries_per_block / 32;
   if (pl.K == 32) qb = 1;  // register budget: 2 x 64 list registers do not fit 2 waves/SIMD
   pl.QB = qb;
   pl.n_qblocks = (int)sskd::ceil_div(nq, 32 * qb);
@@ -749,7 +746,8 @@ Plan make_plan(int64_t n_rows, int nq, int k) {
   // of 8 so that blockIdx % 8 (the XCD label) is a function of the slice
   // (a couple of query blocks - the online /search shape - want one or two workgroups per CU
   // with many tiles each, not a thousand short ones)
-  const int target_wgs = env_int("SSKD_SCAN_TARGET_WGS", pl.n_qblocks <= 2 ? 512 : 1024);
+  const int target_wgs = (tn && tn->target_workgroups > 0) ? tn->target_workgroups
+                                                           : (pl.n_qblocks <= 2 ? 512 : 1024);
   int slices = (int)sskd::ceil_div(target_wgs, pl.n_qblocks);
   slices = (int)sskd::ceil_div(slices, 8) * 8;
   const int max_slices = (int)sskd::ceil_div(pl.n_tiles, pl.waves);  // >= 1 tile per wave
@@ -760,6 +758,11 @@ Plan make_plan(int64_t n_rows, int nq, int k) {
   pl.lists_per_query = pl.n_slices * pl.waves * 2;
   pl.part_elems = (size_t)nq * pl.lists_per_query * pl.K;
   // group-reduce steps before the final merge (see reduce_lists_kernel)
+  // shared pruning pools: when a wave sees only a few tiles (few queries spread over many slices:
+  // the online shape) they cost more than they prune: one query over 1 M rows 1.7 -> 0.33 ms
+  // without them.  Measured crossover (tools/pools_sweep.py, 1 M and 125 k rows, 64..4096
+  // queries): 24-32 tiles per wave; the batch configurations of bench.py have 61.
+  pl.pools = (tn && tn->pruning_pools != 0) ? tn->pruning_pools > 0 : pl.tiles_per_slice >= 24 * pl.waves;
   pl.reduce_lpg = REDUCE_MAX_CAND / pl.K;
   pl.reduce_elems = pl.lists_per_query > MERGE_DIRECT_MAX_LISTS
                         ? (size_t)nq * sskd::ceil_div(pl.lists_per_query, pl.reduce_lpg) * pl.K
@@ -781,12 +784,7 @@ void launch_scan(const Plan& pl, const ScanParams& sp, hipStream_t st) {
 
 template <bool HAS_UB>
 int dispatch_scan(const Plan& pl, const ScanParams& sp, hipStream_t st) {
-  // when a wave sees only a few tiles (few queries spread over many slices: the online shape), the
-  // shared pruning pools cost more than they prune: one query over 1 M rows 1.7 -> 0.33 ms without
-  // them.  Measured crossover (tools/pools_sweep.py, 1 M and 125 k rows, 64..4096 queries):
-  // 24-32 tiles per wave; the batch configurations of bench.py have 61.
-  const int pools_env = env_int("SSKD_SCAN_POOLS", -1);
-  const bool few = pools_env >= 0 ? pools_env == 0 : pl.tiles_per_slice < 24 * pl.waves;
+  const bool few = !pl.pools;
   if (pl.K == 10 && pl.QB == 1 && few) launch_scan<10, 1, HAS_UB, false>(pl, sp, st);
   else if (pl.K == 10 && pl.QB == 2 && few) launch_scan<10, 2, HAS_UB, false>(pl, sp, st);
   else if (pl.K == 10 && pl.QB == 1) launch_scan<10, 1, HAS_UB>(pl, sp, st);
@@ -852,8 +850,13 @@ int sskd_l2_normalize_rows(float* d_x, int64_t n_rows, int dim, void* stream) {
 }
 
 size_t sskd_index_search_workspace_bytes(int64_t n_rows, int nq, int k) {
+  return sskd_index_search_workspace_bytes_ex(n_rows, nq, k, nullptr);
+}
+
+size_t sskd_index_search_workspace_bytes_ex(int64_t n_rows, int nq, int k,
+                                            const sskd_search_tuning* tuning) {
   if (n_rows < 0 || nq <= 0 || k <= 0) return 0;
-  const Plan pl = make_plan(n_rows, nq, k);
+  const Plan pl = make_plan(n_rows, nq, k, tuning);
   return align256(pl.part_elems * sizeof(float)) + align256(pl.part_elems * sizeof(int)) +
          align256((size_t)nq * sizeof(float)) + align256((size_t)nq * sizeof(int)) +
          align256((size_t)nq * (1 + pl.K) * sizeof(int)) +
@@ -863,8 +866,15 @@ size_t sskd_index_search_workspace_bytes(int64_t n_rows, int nq, int k) {
 int sskd_index_search_plan(int64_t n_rows, int nq, int k, int* queries_per_block,
                            int* corpus_passes, int* n_slices, int* waves_per_block,
                            int* scan_passes) {
+  return sskd_index_search_plan_ex(n_rows, nq, k, nullptr, queries_per_block, corpus_passes,
+                                   n_slices, waves_per_block, scan_passes);
+}
+
+int sskd_index_search_plan_ex(int64_t n_rows, int nq, int k, const sskd_search_tuning* tuning,
+                              int* queries_per_block, int* corpus_passes, int* n_slices,
+                              int* waves_per_block, int* scan_passes) {
   SSKD_REQUIRE(n_rows >= 0 && nq > 0 && k > 0, "index_search_plan: bad shape");
-  const Plan pl = make_plan(n_rows, nq, k);
+  const Plan pl = make_plan(n_rows, nq, k, tuning);
   if (queries_per_block) *queries_per_block = 32 * pl.QB;
   if (corpus_passes) *corpus_passes = pl.n_qblocks * pl.passes;
   if (n_slices) *n_slices = pl.n_slices;
@@ -876,15 +886,24 @@ int sskd_index_search_plan(int64_t n_rows, int nq, int k, int* queries_per_block
 int sskd_index_search(const float* d_tiled, int64_t n_rows, const float* d_queries, int nq, int k,
                       int64_t id_offset, float* d_out_scores, int64_t* d_out_ids,
                       void* d_workspace, size_t workspace_bytes, void* stream) {
-  return sskd_index_search_profiled(d_tiled, n_rows, d_queries, nq, k, id_offset, d_out_scores,
-                                    d_out_ids, d_workspace, workspace_bytes, stream, nullptr,
-                                    nullptr);
+  return sskd_index_search_ex(d_tiled, n_rows, d_queries, nq, k, id_offset, d_out_scores,
+                              d_out_ids, d_workspace, workspace_bytes, stream, nullptr, nullptr,
+                              nullptr);
 }
 
 int sskd_index_search_profiled(const float* d_tiled, int64_t n_rows, const float* d_queries, int nq,
                                int k, int64_t id_offset, float* d_out_scores, int64_t* d_out_ids,
                                void* d_workspace, size_t workspace_bytes, void* stream,
                                void* ev_scan_begin, void* ev_scan_end) {
+  return sskd_index_search_ex(d_tiled, n_rows, d_queries, nq, k, id_offset, d_out_scores,
+                              d_out_ids, d_workspace, workspace_bytes, stream, nullptr,
+                              ev_scan_begin, ev_scan_end);
+}
+
+int sskd_index_search_ex(const float* d_tiled, int64_t n_rows, const float* d_queries, int nq,
+                         int k, int64_t id_offset, float* d_out_scores, int64_t* d_out_ids,
+                         void* d_workspace, size_t workspace_bytes, void* stream,
+                         const sskd_search_tuning* tuning, void* ev_scan_begin, void* ev_scan_end) {
   SSKD_REQUIRE(n_rows >= 0, "index_search: n_rows < 0");
   SSKD_REQUIRE(nq >= 0, "index_search: nq < 0");
   SSKD_REQUIRE(k >= 1 && k <= SSKD_K_MAX, "index_search: k=%d outside [1, %d]", k, SSKD_K_MAX);
@@ -899,11 +918,11 @@ int sskd_index_search_profiled(const float* d_tiled, int64_t n_rows, const float
     return sskd::check_launch("fill_empty_kernel");
   }
   SSKD_REQUIRE(d_tiled, "index_search: null index");
-  const size_t need = sskd_index_search_workspace_bytes(n_rows, nq, k);
+  const size_t need = sskd_index_search_workspace_bytes_ex(n_rows, nq, k, tuning);
   if (!d_workspace || workspace_bytes < need)
     return sskd::fail(SSKD_ERR_WORKSPACE, "index_search: workspace %zu B < required %zu B",
                       workspace_bytes, need);
-  const Plan pl = make_plan(n_rows, nq, k);
+  const Plan pl = make_plan(n_rows, nq, k, tuning);
   char* ws = static_cast<char*>(d_workspace);
   float* part_scores = reinterpret_cast<float*>(ws);
   ws += align256(pl.part_elems * sizeof(float));
@@ -974,6 +993,7 @@ int sskd_index_search_profiled(const float* d_tiled, int64_t n_rows, const float
     mp.scores = cand_scores;
     mp.ids = cand_ids;
     mp.list_stride = pl.K;
+    mp.id_list_stride = pl.K;
     mp.q_stride = (int64_t)lists * pl.K;
     mp.k_in = pl.K;
     mp.n_cand = lists * pl.K;
@@ -1133,6 +1153,7 @@ int sskd_topk_merge(const float* d_scores, const int64_t* d_ids, int n_lists, in
   mp.scores = d_scores;
   mp.ids = d_ids;
   mp.list_stride = (int64_t)nq * k_in;
+  mp.id_list_stride = (int64_t)nq * k_in;
   mp.q_stride = k_in;
   mp.k_in = k_in;
   mp.n_cand = n_lists * k_in;
@@ -1148,6 +1169,41 @@ int sskd_topk_merge(const float* d_scores, const int64_t* d_ids, int n_lists, in
   hipLaunchKernelGGL(merge_topk_kernel<int64_t>, dim3((unsigned)sskd::ceil_div(nq, 4)), dim3(256),
                      0, sskd::as_stream(stream), mp);
   return sskd::check_launch("merge_topk_kernel<int64>");
+}
+
+size_t sskd_topk_record_bytes(int nq, int k) {
+  if (nq <= 0 || k <= 0) return 0;
+  return ((size_t)nq * k * (sizeof(int64_t) + sizeof(float)) + 15) & ~(size_t)15;
+}
+
+int sskd_topk_merge_packed(const void* d_records, int n_lists, int nq, int k_in, int k_out,
+                           float* d_out_scores, int64_t* d_out_ids, void* stream) {
+  SSKD_REQUIRE(n_lists >= 1 && nq >= 0 && k_in >= 1 && k_out >= 1, "topk_merge_packed: bad shape");
+  if (nq == 0) return SSKD_OK;
+  SSKD_REQUIRE(d_records && d_out_scores && d_out_ids, "topk_merge_packed: null pointer");
+  SSKD_REQUIRE((reinterpret_cast<uintptr_t>(d_records) & 7) == 0, "topk_merge_packed: records must be 8-byte aligned");
+  const size_t rec = sskd_topk_record_bytes(nq, k_in);
+  const char* base = static_cast<const char*>(d_records);
+  MergeParams<int64_t> mp{};
+  mp.ids = reinterpret_cast<const int64_t*>(base);
+  mp.scores = reinterpret_cast<const float*>(base + (size_t)nq * k_in * sizeof(int64_t));
+  mp.list_stride = (int64_t)(rec / sizeof(float));
+  mp.id_list_stride = (int64_t)(rec / sizeof(int64_t));
+  mp.q_stride = k_in;
+  mp.k_in = k_in;
+  mp.n_cand = n_lists * k_in;
+  mp.nq = nq;
+  mp.out_scores = d_out_scores;
+  mp.out_ids = d_out_ids;
+  mp.out_stride = k_out;
+  mp.out_off = 0;
+  mp.count = k_out;
+  mp.id_offset = 0;
+  mp.ub_scores = nullptr;
+  mp.ub_ids = nullptr;
+  hipLaunchKernelGGL(merge_topk_kernel<int64_t>, dim3((unsigned)sskd::ceil_div(nq, 4)), dim3(256),
+                     0, sskd::as_stream(stream), mp);
+  return sskd::check_launch("merge_topk_kernel<int64> (packed)");
 }
 
 int sskd_similarity(const float* d_q, int nq, const float* d_d, int nd, int dim, float* d_out,

@@ -4,16 +4,18 @@ The reference has a single in-process index (src/serve/app.py:49-66); BASELINE.j
 north star shards the corpus row-wise, so this is the one place the path has a real
 exchange step:
 
-    every rank: scan its shard  ->  (scores fp32, global ids int64)[nq, k]
-    all ranks : all-gather      ->  [G, nq, k]                (1.2 MB / rank at nq=10k, k=10)
-    every rank: merge G*k -> k per query (``sskd_topk_merge``; ties: lower global id)
+    every rank: scan its shard  ->  one packed record { ids int64[nq, k]; scores fp32[nq, k] }
+                                    (the scan's final merge writes straight into the record)
+    all ranks : ONE all-gather  ->  [G] records             (1.2 MB / rank at nq=10k, k=10)
+    every rank: merge G*k -> k per query (``sskd_topk_merge_packed``; ties: lower global id)
 
 The collective goes through ``torch.distributed`` (backend ``nccl`` = RCCL on ROCm) on
-the same stream as the kernels.  ``local_search`` / ``merge`` are injectable so that the
-sharding logic can be exercised with ``gloo`` on CPU in the tests.
+the same stream as the kernels.  ``local_search`` / ``merge`` / ``all_gather`` are injectable
+so that the sharding logic can be exercised with ``gloo`` on CPU in the tests.
 """
 from __future__ import annotations
 
+import inspect
 from typing import Callable, Optional, Tuple
 
 import torch
@@ -26,6 +28,18 @@ def shard_bounds(n_rows: int, world_size: int, rank: int) -> Tuple[int, int]:
     per = -(-n_rows // world_size)
     lo = min(rank * per, n_rows)
     return lo, min(lo + per, n_rows)
+
+
+def record_bytes(nq: int, k: int) -> int:
+    """Bytes of one rank's packed record (``sskd_topk_record_bytes``): ids, scores, pad to 16."""
+    return (nq * k * 12 + 15) // 16 * 16 if nq > 0 and k > 0 else 0
+
+
+def record_views(record: torch.Tensor, nq: int, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``(scores fp32 [nq, k], ids int64 [nq, k])`` views into a packed uint8 record."""
+    ids = record[: nq * k * 8].view(torch.int64).view(nq, k)
+    scores = record[nq * k * 8 : nq * k * 12].view(torch.float32).view(nq, k)
+    return scores, ids
 
 
 def hip_merge(scores: torch.Tensor, ids: torch.Tensor, k_out: int) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -50,32 +64,81 @@ def hip_merge(scores: torch.Tensor, ids: torch.Tensor, k_out: int) -> Tuple[torc
     return out_s, out_i
 
 
+def hip_merge_packed(records: torch.Tensor, g: int, nq: int, k_in: int, k_out: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``[G * record_bytes]`` gathered uint8 records -> ``[nq, k_out]`` (no unpacking copies)."""
+    lib = _native.load()
+    out_s = torch.empty((nq, k_out), dtype=torch.float32, device=records.device)
+    out_i = torch.empty((nq, k_out), dtype=torch.int64, device=records.device)
+    _native.check(
+        lib.sskd_topk_merge_packed(
+            records.data_ptr(), g, nq, k_in, k_out, out_s.data_ptr(), out_i.data_ptr(),
+            int(torch.cuda.current_stream(records.device).cuda_stream),
+        )
+    )
+    return out_s, out_i
+
+
 class ShardedSearcher:
     """Search a corpus whose rows are split over the ranks of a process group."""
 
     def __init__(
         self,
-        local_search: Callable[[torch.Tensor, int], Tuple[torch.Tensor, torch.Tensor]],
+        local_search: Callable[..., Tuple[torch.Tensor, torch.Tensor]],
         group=None,
         merge: Optional[Callable[[torch.Tensor, torch.Tensor, int], Tuple[torch.Tensor, torch.Tensor]]] = None,
+        all_gather: Optional[Callable[[torch.Tensor, torch.Tensor], None]] = None,
     ) -> None:
-        """``local_search(queries, k)`` must return this rank's ``(scores, GLOBAL ids)``
-        (e.g. ``FAISSIndexBuilder(id_offset=lo).search_device``)."""
+        """``local_search(queries, k[, out_scores=, out_ids=])`` must return this rank's
+        ``(scores, GLOBAL ids)`` (e.g. ``FAISSIndexBuilder(id_offset=lo).search_device``); when it
+        accepts ``out_scores`` / ``out_ids`` it writes straight into the packed record.
+        ``merge(scores [G, nq, k], ids [G, nq, k], k)`` replaces the HIP merge (CPU tests);
+        ``all_gather(out, inp)`` replaces ``dist.all_gather_into_tensor`` (e.g. host-staged gloo
+        when several test ranks share one GPU)."""
         self.local_search = local_search
         self.group = group
-        self.merge = merge or hip_merge
+        self.merge = merge
+        self.all_gather = all_gather
+        self.last_world = 1
+
+    def _local_into(self, queries, k, out_s, out_i):
+        fn = self.local_search
+        try:
+            params = inspect.signature(fn).parameters
+        except (TypeError, ValueError):
+            params = {}
+        if "out_scores" in params and "out_ids" in params:
+            s, i = fn(queries, k, out_scores=out_s, out_ids=out_i)
+        else:
+            s, i = fn(queries, k)
+        if s.data_ptr() != out_s.data_ptr():
+            out_s.copy_(s)
+        if i.data_ptr() != out_i.data_ptr():
+            out_i.copy_(i)
 
     def search(self, queries: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
         import torch.distributed as dist
 
-        s, i = self.local_search(queries, k)
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
-            return s, i
+            self.last_world = 1
+            return self.local_search(queries, k)
         world = dist.get_world_size(self.group)
-        nq = s.shape[0]
-        # concatenation form [G * nq, k] (accepted by RCCL and gloo alike), viewed as [G, nq, k]
-        all_s = torch.empty((world * nq, k), dtype=s.dtype, device=s.device)
-        all_i = torch.empty((world * nq, k), dtype=i.dtype, device=i.device)
-        dist.all_gather_into_tensor(all_s, s.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(all_i, i.contiguous(), group=self.group)
-        return self.merge(all_s.view(world, nq, k), all_i.view(world, nq, k), k)
+        self.last_world = world
+        nq = queries.shape[0]
+        rec = record_bytes(nq, k)
+        if rec == 0:
+            return self.local_search(queries, k)
+        dev = queries.device
+        send = torch.empty(rec, dtype=torch.uint8, device=dev)
+        out_s, out_i = record_views(send, nq, k)
+        self._local_into(queries, k, out_s, out_i)
+        recv = torch.empty(world * rec, dtype=torch.uint8, device=dev)
+        if self.all_gather is not None:
+            self.all_gather(recv, send)
+        else:
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+        if self.merge is not None:
+            table = recv.view(world, rec)
+            all_i = table[:, : nq * k * 8].contiguous().view(torch.int64).view(world, nq, k)
+            all_s = table[:, nq * k * 8 : nq * k * 12].contiguous().view(torch.float32).view(world, nq, k)
+            return self.merge(all_s, all_i, k)
+        return hip_merge_packed(recv, world, nq, k, k)

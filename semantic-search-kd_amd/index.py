@@ -83,6 +83,9 @@ class FAISSIndexBuilder:
         self._n = 0
         self._workspace: Optional[torch.Tensor] = None
         self.last_search_path: Optional[str] = None  # which path the last host search() took (diagnostic)
+        # explicit launch tuning (``_native.SearchTuning``) handed to BOTH the workspace query and the
+        # search call; ``None`` = the built-in plan.  There is no environment knob behind the search.
+        self.search_tuning: Optional[_native.SearchTuning] = None
         self.index: Optional[IndexHandle] = None
 
     # ------------------------------------------------------------------ storage
@@ -245,11 +248,12 @@ class FAISSIndexBuilder:
             out_ids = torch.empty((nq, k), dtype=torch.int64, device=self.device)
         if nq == 0:
             return out_scores, out_ids
-        need = int(lib.sskd_index_search_workspace_bytes(self._n, nq, k))
+        tuning = self.search_tuning
+        need = int(lib.sskd_index_search_workspace_bytes_ex(self._n, nq, k, tuning))
         if self._workspace is None or self._workspace.numel() < need:
             self._workspace = torch.empty(max(need, 1), dtype=torch.uint8, device=self.device)
         _native.check(
-            lib.sskd_index_search(
+            lib.sskd_index_search_ex(
                 0 if self._tiled is None else self._tiled.data_ptr(),
                 self._n,
                 q.data_ptr(),
@@ -261,6 +265,9 @@ class FAISSIndexBuilder:
                 self._workspace.data_ptr(),
                 self._workspace.numel(),
                 stream,
+                tuning,
+                None,
+                None,
             )
         )
         return out_scores, out_ids

@@ -52,6 +52,30 @@ def test_search_plan_reports_geometry(native_lib):
     assert rc == 0 and scans.value == 10 and qpb.value == 32
 
 
+def test_tuning_struct_is_explicit_and_sizes_the_workspace(native_lib):
+    """No hidden process-global knobs: the plan depends only on the arguments (and the struct)."""
+    import ctypes as C
+    import os
+
+    from semantic_search_kd_amd import _native
+
+    base = native_lib.sskd_index_search_workspace_bytes(1_000_000, 10_000, 10)
+    os.environ["SSKD_SCAN_QB"] = "1"  # round-1 knob: must be ignored now
+    try:
+        assert native_lib.sskd_index_search_workspace_bytes(1_000_000, 10_000, 10) == base
+    finally:
+        del os.environ["SSKD_SCAN_QB"]
+    assert native_lib.sskd_index_search_workspace_bytes_ex(1_000_000, 10_000, 10, None) == base
+    tn = _native.SearchTuning(32, 0, 0)
+    qpb, passes = C.c_int(), C.c_int()
+    assert native_lib.sskd_index_search_plan_ex(1_000_000, 10_000, 10, tn, qpb, passes, None, None, None) == 0
+    assert qpb.value == 32 and passes.value == 313
+    wide = _native.SearchTuning(0, 4096, 0)  # more slices -> more partial lists -> larger workspace
+    assert native_lib.sskd_index_search_workspace_bytes_ex(1_000_000, 10_000, 10, wide) > base
+    assert native_lib.sskd_topk_record_bytes(10_000, 10) == 1_200_000
+    assert native_lib.sskd_topk_record_bytes(3, 5) == 192  # 180 B padded to 16
+
+
 def test_invalid_arguments_are_reported_not_thrown(native_lib):
     rc = native_lib.sskd_index_search(None, 10, None, 1, 0, 0, None, None, None, 0, None)
     assert rc == 1

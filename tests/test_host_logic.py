@@ -172,3 +172,26 @@ def test_student_without_gpu_fails_loudly():
 
     with pytest.raises(RuntimeError, match="no CPU path|MI355X"):
         StudentModel("some/dir", device=None)
+
+
+def test_bench_self_launches_ranks_from_a_bare_shell():
+    """``python bench.py --gpus 2`` with no RANK in the environment starts torch.distributed.run as
+    a child before touching the GPU and returns its exit code (checked here with the CPU-only
+    ``--launch-check`` leg: rendezvous at 127.0.0.1 + one all-gather, rank 0 prints one JSON line)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from conftest import REPO
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--launch-check"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"launch_check": True, "ranks": 2}
+    # a failing child propagates its exit code
+    bad = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--launch-check", "--steps", "x"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0

@@ -456,3 +456,46 @@ def test_cfg3_full_corpus_8_8m_rows(gpu, native_lib):
     Ds, Is = shard.search(q, k=10)
     ref_s, ref_i = oracle.topk_fma(q, corpus[lo:hi], 10, id_offset=lo)
     assert np.array_equal(Is, ref_i) and np.array_equal(Ds, ref_s) and Is.min() >= lo
+
+
+def test_packed_merge_equals_plain_merge(gpu, native_lib):
+    """sskd_topk_merge_packed over the records ONE all-gather moves == sskd_topk_merge; odd nq * k
+    exercises the record padding."""
+    from semantic_search_kd_amd.dist import hip_merge_packed, record_bytes, record_views
+
+    corpus = oracle.seeded_unit_rows(1500, 384, 61)
+    for nq, k in ((37, 10), (3, 5), (1, 1)):
+        queries = oracle.seeded_unit_rows(nq, 384, 62 + nq)
+        bounds = [0, 500, 501, 1500]
+        g = len(bounds) - 1
+        rec = record_bytes(nq, k)
+        assert rec == native_lib.sskd_topk_record_bytes(nq, k) and rec % 16 == 0
+        records = torch.zeros(g * rec, dtype=torch.uint8, device="cuda")
+        for r, (lo, hi) in enumerate(zip(bounds[:-1], bounds[1:])):
+            s, i = capi_search(native_lib, tile_corpus(native_lib, corpus[lo:hi]), hi - lo, queries, k, id_offset=lo)
+            vs, vi = record_views(records[r * rec : (r + 1) * rec], nq, k)
+            vs.copy_(torch.from_numpy(s))
+            vi.copy_(torch.from_numpy(i))
+        out_s, out_i = hip_merge_packed(records, g, nq, k, k)
+        whole_s, whole_i = oracle.topk_fma(queries, corpus, k)
+        assert np.array_equal(out_i.cpu().numpy(), whole_i) and np.array_equal(out_s.cpu().numpy(), whole_s)
+
+
+def test_search_tuning_struct_changes_plan_not_results(gpu, native_lib):
+    """The launch tuning is an explicit argument handed to the workspace query AND the search (no
+    environment knobs); every setting returns the same bits."""
+    corpus = oracle.seeded_unit_rows(20000, 384, 71)
+    queries = oracle.seeded_unit_rows(130, 384, 72)
+    ref_s, ref_i = oracle.topk_fma(queries, corpus, 10)
+    index = FAISSIndexBuilder(embedding_dim=384, metric="ip", device="cuda:0")
+    index.add(corpus)
+    q = torch.from_numpy(queries).cuda()
+    seen = set()
+    for tn in (None, _native.SearchTuning(32, 0, 0), _native.SearchTuning(64, 256, 1), _native.SearchTuning(0, 2048, -1)):
+        index.search_tuning = tn
+        s, i = index.search_device(q, 10, normalize_queries=False)
+        assert np.array_equal(i.cpu().numpy(), ref_i) and np.array_equal(s.cpu().numpy(), ref_s)
+        plan = [ctypes.c_int() for _ in range(5)]
+        _native.check(native_lib.sskd_index_search_plan_ex(20000, 130, 10, tn, *plan))
+        seen.add((plan[0].value, plan[2].value))
+    assert len(seen) >= 3  # the tuning really changed queries-per-block / slices

@@ -1,8 +1,14 @@
-"""Row-sharded search over world_size-2 ``gloo`` process groups on CPU.
+"""Row-sharded search over world_size-2 process groups.
 
-Exercises the N > 1 plumbing of ``ShardedSearcher`` — shard bounds, global id offsets, the
-all-gather layout ``[G, nq, k]`` and the merge — with the HIP calls replaced by the oracle
-(tests may use the oracle; the product default is ``hip_merge`` / ``search_device``).
+CPU (``gloo``): the N > 1 plumbing of ``ShardedSearcher`` — shard bounds, global id offsets, the
+packed per-rank record, ONE all-gather and the merge — with the HIP calls replaced by the oracle
+(tests may use the oracle; the product default is ``search_device`` + ``sskd_topk_merge_packed``).
+
+GPU (``-m gpu``): the PRODUCT path end to end in two processes — ``FAISSIndexBuilder.search_device``
+writing into the packed record, the all-gather and the HIP packed merge.  On a box with >= 2 GPUs
+the collective is RCCL (backend ``nccl``); on the one-GPU test box both ranks share cuda:0 (RCCL
+refuses two ranks on one device), so the records cross through a host-staged ``gloo`` all-gather —
+everything else is the code bench.py runs.
 """
 import os
 import socket
@@ -66,3 +72,62 @@ def test_sharded_search_equals_unsharded(tmp_path, n, nq, k):
     for r in range(world):
         got = np.load(tmp_path / f"rank{r}.npz")
         assert np.array_equal(got["i"], ref_i) and np.array_equal(got["s"], ref_s)
+
+
+def _gpu_worker(rank, world, port, n, nq, k, out_dir, backend):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from semantic_search_kd_amd import FAISSIndexBuilder
+
+        corpus = oracle.seeded_unit_rows(n, 384, 1234)
+        queries = torch.from_numpy(oracle.seeded_unit_rows(nq, 384, 4321)).to(dev)
+        lo, hi = shard_bounds(n, world, rank)
+        index = FAISSIndexBuilder(embedding_dim=384, metric="ip", device=str(dev), id_offset=lo)
+        index.add(corpus[lo:hi])
+
+        def local_search(q, kk, out_scores=None, out_ids=None):
+            return index.search_device(q, kk, normalize_queries=False, out_scores=out_scores, out_ids=out_ids)
+
+        def host_staged_gather(out, inp):  # one GPU shared by both ranks: gloo moves host copies
+            host_out = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(host_out, inp.cpu())
+            out.copy_(host_out)
+
+        searcher = ShardedSearcher(local_search, all_gather=None if backend == "nccl" else host_staged_gather)
+        s, i = searcher.search(queries, k)
+        torch.cuda.synchronize()
+        assert searcher.last_world == world
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), s=s.cpu().numpy(), i=i.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,nq,k", [(5000, 70, 10), (5, 3, 10)])
+def test_product_sharded_search_two_ranks(tmp_path, n, nq, k):
+    """search_device -> packed record -> all-gather -> sskd_topk_merge_packed in 2 processes."""
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    world = 2
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, _PORTS.setdefault((n, nq), _free_port()), n, nq, k, str(tmp_path), backend))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    corpus = oracle.seeded_unit_rows(n, 384, 1234)
+    queries = oracle.seeded_unit_rows(nq, 384, 4321)
+    ref_s, ref_i = oracle.topk_fma(queries, corpus, k)
+    for r in range(world):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        assert np.array_equal(got["i"], ref_i) and np.array_equal(got["s"], ref_s)
+
+
+_PORTS = {}

@@ -1,5 +1,4 @@
 """Diagnostic: batch search time vs number of queries, with the scan's pruning pools forced on / off."""
-import os
 import subprocess
 import sys
 import time
@@ -9,12 +8,13 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     import torch
 
     sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-    from semantic_search_kd_amd import FAISSIndexBuilder
+    from semantic_search_kd_amd import FAISSIndexBuilder, _native
 
     n = int(sys.argv[2])
     c = torch.nn.functional.normalize(torch.randn(n, 384, device="cuda"), dim=1)
     ib = FAISSIndexBuilder(384, "Flat", "cosine")
     ib.add(c)
+    ib.search_tuning = _native.SearchTuning(0, 0, 1 if sys.argv[3] == "1" else -1)
     for nq in [64, 128, 256, 512, 1024, 2048, 4096]:
         q = torch.nn.functional.normalize(torch.randn(nq, 384, device="cuda"), dim=1)
         for _ in range(2):
@@ -29,4 +29,4 @@ else:
     for n in (1_000_000, 125_000):
         for pools in ("1", "0"):
             print(f"n={n} pools={pools}", flush=True)
-            subprocess.run([sys.executable, __file__, "child", str(n)], env=dict(os.environ, SSKD_SCAN_POOLS=pools), check=True)
+            subprocess.run([sys.executable, __file__, "child", str(n), pools], check=True)
