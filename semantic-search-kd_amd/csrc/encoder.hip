@@ -63,23 +63,22 @@ __device__ inline bf16x8 zero_bf8() {
 
 __device__ inline float bf2f(__bf16 v) { return (float)v; }
 
-// erf-GELU (HF "gelu") = 0.5 x (1 + erf(x / sqrt 2)), erf by Abramowitz-Stegun 7.1.25
-// (|err| <= 2.5e-5, 80x below the bf16 half-ulp of the value produced):
-//   erf(z) = 1 - (a1 t + a2 t^2 + a3 t^3) exp(-z^2),  t = 1 / (1 + p z),  z = |x| / sqrt 2
-// written around u = |x| sqrt(log2(e) / 2) so that exp(-z^2) = exp2(-u^2) needs no extra
-// multiply: 10 VALU + 2 transcendental instructions, no compare / select.
+// erf-GELU (HF "gelu") = x Phi(x), evaluated as x * sigmoid(x (a + b x^2 + c x^4)) with (a, b, c)
+// fitted (minimax on [-8, 8]) to the exact erf form: max |error| 2.6e-5 - the same bound as the
+// Abramowitz-Stegun 7.1.25 erf it replaces, 80x below the bf16 half-ulp of the value produced -
+// in 7 VALU + 2 transcendental instructions instead of 10 + 2 (the MLP is bound by the SIMD's
+// instruction issue, not by the matrix pipe: every VALU instruction per element is 16 x 4 issue
+// cycles per chunk).  The polynomial is evaluated on clamp(x, -8, 8) (beyond, sigmoid is 0 or 1 to
+// fp32 precision and the quartic term would turn over at |x| > 11); coefficients carry the
+// -log2(e) of exp(-t) = exp2(-t log2 e).
 __device__ inline float gelu_erf(float x) {
-  constexpr float KU = 0.84932180028801904f;             // sqrt(log2(e) / 2)
-  constexpr float PU = 0.47047f * 0.70710678118654752f / KU;  // p z = PU u
-  const float u = fabsf(x) * KU;
-  const float t = __builtin_amdgcn_rcpf(fmaf(PU, u, 1.0f));
-  float p = fmaf(0.7478556f, t, -0.0958798f);
-  p = fmaf(p, t, 0.3480242f);
-  p *= t;
-  const float e = __builtin_amdgcn_exp2f(-(u * u));
-  const float erf_abs = fmaf(-p, e, 1.0f);
-  const float hx = 0.5f * x;
-  return fmaf(fabsf(hx), erf_abs, hx);
+  constexpr float A = -2.3011212f, B = -0.10677574f, C = 0.0010142655f;
+  const float xc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);
+  const float x2 = xc * xc;
+  float q = fmaf(C, x2, B);
+  q = fmaf(q, x2, A);
+  const float e = __builtin_amdgcn_exp2f(q * xc);
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 // Exchange with lane ^ 32 in the VALU (v_permlane32_swap) instead of __shfl_xor's ds_bpermute,
@@ -264,33 +263,41 @@ struct GemmN384Params {
 constexpr int KS2 = 12;                  // k-steps of one 192-wide K chunk
 constexpr int HTILE_VEC = 32 * 192 / 8;  // bf16x8 vectors of one [32 x 192] weight half-tile (12 KiB)
 
-// N = 384 GEMM (K = 192 * KC2) with fused bias + residual + LayerNorm epilogue.
-// Workgroup = 8 waves = 128 tokens: wave = (token tile tg, feature half nh); each wave
+// N = 384 GEMM (K = 192 * KC2) with fused bias + residual + LayerNorm epilogue, for the 4 token
+// tiles tt0 .. tt0 + 3 of a 512-thread workgroup.
+// 8 waves = 4 token tiles x 2 feature halves: wave = (token tile tg, feature half nh); each wave
 // accumulates its 6 output tiles (192 features of its tokens) in 96 registers, the LayerNorm
 // statistics of the two halves meet through 2 KiB of LDS.  K is walked in 192-wide chunks so
 // that activations (48 VGPRs) + accumulators + fragment prefetch fit 2 waves/SIMD.
+// LDS (caller-provided): wl = 2 buffers x [feature half][2 tiles][768 vectors] = 96 KiB,
+// stats = [128] float2 pairs x 2, par = [3][384] floats (bias, gamma, beta; filled here).
+// `n_valid` = how many of the 4 token tiles exist (the others compute on tile tt0 and store
+// nothing).  Every wave of the workgroup must call this (it contains workgroup barriers).
+constexpr int GEMM384_WL_VEC = 2 * 2 * 2 * HTILE_VEC;  // bf16x8 vectors of the weight staging area
+
 template <int KC2>
-__global__ __launch_bounds__(512) void gemm_n384_ln_kernel(GemmN384Params p) {
-  // per buffer: [feature half][2 tiles][768 vectors] = 48 KiB
-  __shared__ bf16x8 wlds[2][2][2][HTILE_VEC];
-  __shared__ float2 stats[128][2];
-  __shared__ __attribute__((aligned(16))) float par_lds[3][H];  // bias, gamma, beta
+__device__ inline void gemm_n384_ln_block(const GemmN384Params& p, int64_t tt0, int n_valid,
+                                          bf16x8* __restrict__ wl, float2* __restrict__ stats,
+                                          float* __restrict__ par) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tg = wave & 3, nh = wave >> 2;
   const int r = lane & 31, h = lane >> 5;
-  const int tt = blockIdx.x * 4 + tg;
+  const bool valid = tg < n_valid;  // wave-uniform
+  const int64_t tt = tt0 + (valid ? tg : 0);
   constexpr int KTOT = KS2 * KC2;  // k-steps per output tile
   constexpr int NIT = KC2 * 3;     // iterations: (K chunk, pair of tiles)
+  // wl[buf][nh][t2][HTILE_VEC]
+  auto wtile = [&](int buf, int half, int t2) { return wl + ((buf * 2 + half) * 2 + t2) * HTILE_VEC; };
 
   f32x16 acc[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) acc[j] = zero16();
   for (int i = tid; i < H; i += 512) {
-    par_lds[0][i] = p.bias[i];
-    par_lds[1][i] = p.gamma[i];
-    par_lds[2][i] = p.beta[i];
+    par[i] = p.bias[i];
+    par[H + i] = p.gamma[i];
+    par[2 * H + i] = p.beta[i];
   }
 
   // iteration it = (kc, jp): every feature half stages its tiles 6 nh + 2 jp + {0, 1}, K chunk kc.
@@ -303,8 +310,8 @@ __global__ __launch_bounds__(512) void gemm_n384_ln_kernel(GemmN384Params p) {
     return p.w + ((int64_t)nt * KTOT + KS2 * kc) * 64 + off;
   };
   bf16x8 stage[6];
-  bf16x8* const lds_flat0 = &wlds[0][0][0][0];
-  bf16x8* const lds_flat1 = &wlds[1][0][0][0];
+  bf16x8* const lds_flat0 = wl;
+  bf16x8* const lds_flat1 = wl + 4 * HTILE_VEC;
 #pragma unroll
   for (int i = 0; i < 6; ++i) lds_flat0[tid + 512 * i] = *stage_src(0, tid + 512 * i);
   __syncthreads();
@@ -327,8 +334,8 @@ __global__ __launch_bounds__(512) void gemm_n384_ln_kernel(GemmN384Params p) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) stage[i] = *stage_src(it + 1, tid + 512 * i);
       }
-      acc[2 * jp] = tile_mfma<KS2, 4>(&wlds[cur][nh][0][0] + lane, x, acc[2 * jp]);
-      acc[2 * jp + 1] = tile_mfma<KS2, 4>(&wlds[cur][nh][1][0] + lane, x, acc[2 * jp + 1]);
+      acc[2 * jp] = tile_mfma<KS2, 4>(wtile(cur, nh, 0) + lane, x, acc[2 * jp]);
+      acc[2 * jp + 1] = tile_mfma<KS2, 4>(wtile(cur, nh, 1) + lane, x, acc[2 * jp + 1]);
       if (more) {
         bf16x8* dst = cur ? lds_flat0 : lds_flat1;
 #pragma unroll
@@ -348,7 +355,7 @@ __global__ __launch_bounds__(512) void gemm_n384_ln_kernel(GemmN384Params p) {
     const int nt = nh * 6 + j;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const f32x4 b = *reinterpret_cast<const f32x4*>(&par_lds[0][nt * 32 + 8 * g + 4 * h]);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(&par[nt * 32 + 8 * g + 4 * h]);
       const bf16x4 rr = *reinterpret_cast<const bf16x4*>(
           res + ((int64_t)((2 * nt + (g >> 1)) * 64 + r + 32 * (g & 1))) * 8 + 4 * h);
 #pragma unroll
@@ -362,25 +369,35 @@ __global__ __launch_bounds__(512) void gemm_n384_ln_kernel(GemmN384Params p) {
   }
   sum = pair_sum(sum);
   sq = pair_sum(sq);
-  if (h == 0) stats[tg * 32 + r][nh] = make_float2(sum, sq);
+  if (h == 0) stats[(tg * 32 + r) * 2 + nh] = make_float2(sum, sq);
   __syncthreads();
-  const float2 s0 = stats[tg * 32 + r][0], s1 = stats[tg * 32 + r][1];
+  const float2 s0 = stats[(tg * 32 + r) * 2], s1 = stats[(tg * 32 + r) * 2 + 1];
   const float mean = (s0.x + s1.x) * (1.0f / H);
   const float var = fmaxf((s0.y + s1.y) * (1.0f / H) - mean * mean, 0.f);
   const float rstd = rsqrtf(var + p.eps);
+  if (valid) {
 #pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const int nt = nh * 6 + j;
-    f32x4 v[4];
+    for (int j = 0; j < 6; ++j) {
+      const int nt = nh * 6 + j;
+      f32x4 v[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 ga = *reinterpret_cast<const f32x4*>(&par_lds[1][nt * 32 + 8 * g + 4 * h]);
-      const f32x4 be = *reinterpret_cast<const f32x4*>(&par_lds[2][nt * 32 + 8 * g + 4 * h]);
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(&par[H + nt * 32 + 8 * g + 4 * h]);
+        const f32x4 be = *reinterpret_cast<const f32x4*>(&par[2 * H + nt * 32 + 8 * g + 4 * h]);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[g][e] = (acc[j][4 * g + e] - mean) * rstd * ga[e] + be[e];
+        for (int e = 0; e < 4; ++e) v[g][e] = (acc[j][4 * g + e] - mean) * rstd * ga[e] + be[e];
+      }
+      store_tile_frag(p.out + frag_base(tt, 2 * nt, KSTEPS) * 8, v, lane);
     }
-    store_tile_frag(p.out + frag_base(tt, 2 * nt, KSTEPS) * 8, v, lane);
   }
+}
+
+template <int KC2>
+__global__ __launch_bounds__(512) void gemm_n384_ln_kernel(GemmN384Params p) {
+  __shared__ bf16x8 wlds[GEMM384_WL_VEC];  // 96 KiB
+  __shared__ float2 stats[128 * 2];
+  __shared__ __attribute__((aligned(16))) float par_lds[3 * H];  // bias, gamma, beta
+  gemm_n384_ln_block<KC2>(p, (int64_t)blockIdx.x * 4, 4, wlds, stats, par_lds);
 }
 
 // ------------------------------------------------------------------------- //
@@ -1161,16 +1178,10 @@ int run_layers(const sskd_encoder_config* cfg, const sskd_encoder_weights* w, co
     const int qa_tiles = qa.spw * nkt;
     const int qa_rows = (B + qa.spw - 1) / qa.spw;  // workgroup rows
     const size_t qa_lds_bytes = 3 * WTILE_VEC * sizeof(bf16x8) +
-                                (size_t)qa_tiles * ((nkt > 8 ? 2 : 4) * 128 * sizeof(bf16x8) + 32 * sizeof(float)) + 2 * 96 * sizeof(float);
-    auto qa_kernel = nkt > 8 ? qkv_attention_kernel<true> : qkv_attention_kernel<false>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(qa_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)qa_lds_bytes);
+                          (size_t)qa_tiles * ((nkt > 8 ? 2 : 4) * 128 * sizeof(bf16x8) + 32 * sizeof(float)) + 2 * 96 * sizeof(float);
     // all 12 heads per workgroup once there are enough batch rows to fill the chip; fewer heads
     // per workgroup (more workgroups) for small batches
     qa.hpw = qa_rows >= 256 ? 12 : (qa_rows >= 64 ? 4 : 1);
-    hipLaunchKernelGGL(qa_kernel, dim3(qa_rows * (NH / qa.hpw)), dim3(512), qa_lds_bytes, st, qa);
-    if ((rc = sskd::check_launch("qkv_attention_kernel")) != SSKD_OK) return rc;
-
     GemmN384Params o{};
     o.x = reinterpret_cast<const bf16x8*>(ws.ctx);
     o.w = static_cast<const bf16x8*>(lw.wo);
@@ -1180,6 +1191,16 @@ int run_layers(const sskd_encoder_config* cfg, const sskd_encoder_weights* w, co
     o.beta = lw.ln1_b;
     o.eps = cfg->layer_norm_eps;
     o.out = x1;
+    auto qa_kernel = nkt > 8 ? qkv_attention_kernel<true> : qkv_attention_kernel<false>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(qa_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)qa_lds_bytes);
+    hipLaunchKernelGGL(qa_kernel, dim3(qa_rows * (NH / qa.hpw)), dim3(512), qa_lds_bytes, st, qa);
+    if ((rc = sskd::check_launch("qkv_attention_kernel")) != SSKD_OK) return rc;
+
+    // (Running this GEMM in the attention workgroup's tail - it owns all heads of its 256 tokens -
+    // was built and measured: 5.5 % slower end to end on one box (7.92 vs 7.51 ms).  The step is
+    // bound by the CUs' load / store paths (345 MB per layer at 3.8 TB/s), every workgroup reaches
+    // its tail at the same time, and the tail then runs the same bytes with 1 workgroup per CU.)
     hipLaunchKernelGGL(gemm_n384_ln_kernel<2>, dim3(Tpad / 128), dim3(512), 0, st, o);
     if ((rc = sskd::check_launch("gemm_n384_ln_kernel<2>")) != SSKD_OK) return rc;
 

@@ -491,7 +491,7 @@ def test_search_tuning_struct_changes_plan_not_results(gpu, native_lib):
     index.add(corpus)
     q = torch.from_numpy(queries).cuda()
     seen = set()
-    for tn in (None, _native.SearchTuning(32, 0, 0), _native.SearchTuning(64, 256, 1), _native.SearchTuning(0, 2048, -1)):
+    for tn in (None, _native.SearchTuning(32, 0, 0), _native.SearchTuning(64, 16, 1), _native.SearchTuning(0, 2048, -1)):
         index.search_tuning = tn
         s, i = index.search_device(q, 10, normalize_queries=False)
         assert np.array_equal(i.cpu().numpy(), ref_i) and np.array_equal(s.cpu().numpy(), ref_s)
