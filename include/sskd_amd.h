@@ -250,6 +250,53 @@ int sskd_encoder_hidden(const sskd_encoder_config* cfg, const sskd_encoder_weigh
                         void* d_hidden_bf16, void* d_workspace, size_t workspace_bytes,
                         void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * Sequence packing (varlen / "cu_seqlens"): SentenceTransformer.encode pads every text of a
+ * batch to the longest one (reference: tests/test_model_validation.py:80-110); here whole
+ * sequences are concatenated into rows of `capacity` tokens (<= 256, multiple of 32) and
+ * attention is block-diagonal per sequence, so only the tail of a row is padding.
+ * ------------------------------------------------------------------------- */
+
+/* HOST function.  Best-fit-decreasing placement of n_seq sequences (1 <= lengths[i] <= capacity)
+ * into rows.  table[4 i .. 4 i + 3] = { row, lo, hi, i }: sequence i occupies tokens [lo, hi) of
+ * `row`.  *n_rows = rows used. */
+int sskd_pack_plan(const int32_t* lengths, int n_seq, int capacity, int32_t* table, int* n_rows);
+
+/* Lay the flat token stream out as packed rows: d_flat_ids holds the sequences back to back,
+ * d_cu_seqlens[n_seq + 1] their start offsets, d_table the (device copy of the) plan.
+ * Outputs int32 [n_rows, capacity]: d_ids (0 = [PAD]) and d_seg (lo | hi << 16 per token,
+ * 0 for padding). */
+int sskd_pack_tokens(const int32_t* d_flat_ids, const int32_t* d_cu_seqlens, const int32_t* d_table,
+                     int n_seq, int n_rows, int capacity, int32_t* d_ids, int32_t* d_seg, void* stream);
+
+/* sskd_encoder_forward over packed rows; position ids restart at every sequence.  d_out fp32
+ * [*, 384]: row table[4 i + 3] receives the embedding of sequence i.  Workspace:
+ * sskd_encoder_workspace_bytes(cfg, n_rows, capacity). */
+int sskd_encoder_forward_packed(const sskd_encoder_config* cfg, const sskd_encoder_weights* w,
+                                const int32_t* d_ids, const int32_t* d_seg, int n_rows, int capacity,
+                                const int32_t* d_table, int n_seq, int normalize, float* d_out,
+                                void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Host WordPiece tokenizer (uncased BERT): replaces the `tokenizers` call inside
+ * SentenceTransformer.encode for ASCII text (reference: AutoTokenizer use src/utils/chunk.py:26;
+ * vocabulary / special ids SURVEY.md §8c).  HOST functions, multi-threaded, no device work.
+ * ------------------------------------------------------------------------- */
+
+/* vocab_blob: the vocabulary tokens in id order separated by '\n' (vocab.txt layout). */
+int sskd_tokenizer_create(const char* vocab_blob, int64_t blob_bytes, void** handle);
+void sskd_tokenizer_destroy(void* handle);
+
+/* Tokenise n_texts UTF-8 texts: text i = text_blob[offsets[i], offsets[i+1]) (NUL bytes inside are
+ * ignored, so texts may simply be NUL-joined).  Emits "[CLS] pieces [SEP]" ids truncated to
+ * max_len (the closing [SEP] is kept) back to back into out_ids; out_lengths[i] = ids of text i.
+ * A text containing any non-ASCII byte is not tokenised: out_needs_unicode[i] = 1,
+ * out_lengths[i] = 0 - the caller must route it through a Unicode-complete tokenizer.
+ * *out_total = ids written; SSKD_ERR_WORKSPACE if out_capacity is too small. */
+int sskd_tokenizer_encode(void* handle, const char* text_blob, const int64_t* offsets, int n_texts,
+                          int max_len, int n_threads, int32_t* out_ids, int64_t out_capacity,
+                          int32_t* out_lengths, uint8_t* out_needs_unicode, int64_t* out_total);
+
 #ifdef __cplusplus
 }
 #endif

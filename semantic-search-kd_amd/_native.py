@@ -100,6 +100,15 @@ SIGNATURES = {
         _i,
         [C.POINTER(EncoderConfig), C.POINTER(EncoderWeights), _vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp],
     ),
+    "sskd_pack_plan": (_i, [_vp, _i, _i, _vp, _ip]),
+    "sskd_pack_tokens": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "sskd_encoder_forward_packed": (
+        _i,
+        [C.POINTER(EncoderConfig), C.POINTER(EncoderWeights), _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _sz, _vp],
+    ),
+    "sskd_tokenizer_create": (_i, [C.c_char_p, _i64, C.POINTER(C.c_void_p)]),
+    "sskd_tokenizer_destroy": (None, [_vp]),
+    "sskd_tokenizer_encode": (_i, [_vp, C.c_char_p, _vp, _i, _i, _i, _vp, _i64, _vp, _vp, C.POINTER(_i64)]),
     "sskd_encoder_hidden": (
         _i,
         [C.POINTER(EncoderConfig), C.POINTER(EncoderWeights), _vp, _vp, _i, _i, _vp, _vp, _sz, _vp],

@@ -72,6 +72,8 @@ def bench_encode(device, world: int, steps: int, warmup: int, barrier, batch: in
         "unit_norm_ok": bool(torch.allclose(norms, torch.ones_like(norms), atol=1e-3)),
         # rank 0's own rate on MS MARCO-shaped ragged lengths (per GPU, not aggregated)
         "ragged": bench_encode_ragged(enc, device) if ragged else None,
+        # and end to end from Python strings (tokenise + H2D + forward + D2H) through StudentModel
+        "text": bench_encode_text(enc, device) if text else None,
     }
 
 
@@ -83,47 +85,102 @@ def marco_like_lengths(n: int, seed: int = 7, max_len: int = 256) -> np.ndarray:
     return np.clip(np.rint(lens), 8, max_len).astype(np.int64)
 
 
-def bench_encode_ragged(enc: Mi355xSentenceEncoder, device, passes: int = 2, n_docs: int = 32768, batch: int = 512):
-    """docs/s on ragged lengths the way ``encode()`` runs them: sort by length (longest first),
-    batches of ``batch``, each padded to its longest member (rounded up to the 32-token tile).
-    FLOPs are counted on real tokens only.  (The sample must be large against the batch size: with
-    only a few batches each one spans a wide range of lengths and the padding share is inflated.
-    Cutting batches at tile-count boundaries instead was measured: no gain at this size.)"""
+def bench_encode_ragged(enc: Mi355xSentenceEncoder, device, passes: int = 2, n_docs: int = 32768):
+    """docs/s on ragged lengths through the varlen path (``encode_ragged``): whole sequences packed into
+    256-token rows, launches cut by a token budget; inputs are host token ids (flat int32 stream +
+    lengths), so the H2D copies of the ids are inside the timed region.  FLOPs are counted on real
+    tokens only (attention term with each sequence's own length)."""
     cfg = enc.config
-    lens = np.sort(marco_like_lengths(n_docs))[::-1]
-    g = torch.Generator(device=device).manual_seed(11)
-    batches = []
-    flops = 0.0
-    for b0 in range(0, n_docs, batch):
-        bl = lens[b0:b0 + batch]
-        S = int(-(-int(bl[0]) // 32) * 32)
-        ids = torch.randint(999, cfg.vocab_size, (len(bl), S), generator=g, device=device, dtype=torch.int32)
-        ids[:, 0] = 101
-        lt = torch.from_numpy(bl.copy()).to(device)
-        mask = (torch.arange(S, device=device)[None, :] < lt[:, None]).to(torch.int32)
-        ids = ids * mask
-        batches.append((ids, mask, torch.empty((len(bl), cfg.hidden_size), dtype=torch.float32, device=device)))
-        flops += float(sum(encoder_flops(int(l), int(l), cfg) for l in bl))
-    def one_pass():
-        for ids, mask, out in batches:
-            enc.encode_token_ids(ids, mask, normalize=True, out=out)
-    one_pass()
+    lens = marco_like_lengths(n_docs).astype(np.int32)  # arrival order: NOT sorted
+    rng = np.random.default_rng(11)
+    flat = rng.integers(999, cfg.vocab_size, size=int(lens.sum()), dtype=np.int64).astype(np.int32)
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    flat[starts] = 101
+    out = torch.empty((n_docs, cfg.hidden_size), dtype=torch.float32, device=device)
+    flops = float(sum(encoder_flops(int(l), int(l), cfg) for l in lens))
+    enc.encode_ragged(flat, lens, out=out)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(passes):
-        one_pass()
+        enc.encode_ragged(flat, lens, out=out)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / passes
-    padded = sum(int(i.numel()) for i, _, _ in batches)
     return {
         "value": round(n_docs / dt, 1),
         "unit": "docs/s",
-        "workload": f"{n_docs} passages, lengths clipped log-normal (mean {lens.mean():.0f}, median "
-                    f"{int(np.median(lens))}, max {int(lens.max())} tokens; SURVEY.md §8d assumption), "
-                    f"length-sorted batches of {batch} padded to the longest member",
+        "workload": f"{n_docs} passages in arrival order, lengths clipped log-normal (mean {lens.mean():.0f}, median "
+                    f"{int(np.median(lens))}, max {int(lens.max())} tokens; SURVEY.md §8d assumption), packed into "
+                    f"256-token rows (block-diagonal attention), host token ids in",
         "real_tokens_per_s": round(float(lens.sum()) / dt, 1),
-        "padding_overhead": round(padded / float(lens.sum()) - 1.0, 4),
+        "padding_overhead": round(enc.last_encode_stats["padding_overhead"], 4),
         "mfma_frac_real_tokens": round(flops / dt / 1e12 / MFMA_BF16_PEAK_TF, 4),
+    }
+
+
+def synthetic_vocab(size: int = 30522):
+    """A WordPiece vocabulary of the e5 size made of pronounceable pseudo-words (no real vocab is
+    on disk offline): BERT's special-token ids, then whole words and ``##`` continuations."""
+    rng = np.random.default_rng(5)
+    cons, vow = "bcdfghjklmnprstvwz", "aeiou"
+    words = ["[PAD]"] + [f"[unused{i}]" for i in range(99)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"]
+    words += [f"[unused{i}]" for i in range(99, 994)]   # ids 104 .. 998 as in bert-base-uncased
+    words += list("abcdefghijklmnopqrstuvwxyz0123456789.,;:!?'-")
+    seen = set(words)
+    while len(words) < size:
+        n_syl = int(rng.integers(1, 4))
+        w = "".join(cons[rng.integers(len(cons))] + vow[rng.integers(len(vow))] for _ in range(n_syl))
+        if rng.random() < 0.3:
+            w = "##" + w
+        if w not in seen:
+            seen.add(w)
+            words.append(w)
+    return words
+
+
+def synthetic_passages(vocab, n_docs: int, seed: int = 3):
+    """MS MARCO-shaped English-like text over the synthetic vocabulary: word counts such that the
+    WordPiece lengths follow ``marco_like_lengths`` (plus the ``passage: `` prefix of the e5 path)."""
+    rng = np.random.default_rng(seed)
+    whole = np.array([w for w in vocab[1000:] if not w.startswith("##") and len(w) > 1])
+    lens = np.maximum(marco_like_lengths(n_docs, seed=seed) - 5, 1)
+    picks = rng.integers(0, whole.size, size=int(lens.sum()))
+    docs, pos = [], 0
+    for n in lens:
+        docs.append(" ".join(whole[picks[pos : pos + n]]))
+        pos += int(n)
+    return docs
+
+
+def bench_encode_text(enc: Mi355xSentenceEncoder, device, n_docs: int = 32768, passes: int = 2):
+    """docs/s of ``StudentModel.encode_documents(list_of_str)`` end to end - tokenise (background
+    thread) + H2D + packed forward + D2H to NumPy - the call ``build_from_parquet`` makes
+    (reference: scripts/build_faiss_index.py:55-62 with its default batch_size=32)."""
+    from .encoder import build_wordpiece_tokenizer
+    from .student import StudentModel
+
+    vocab = synthetic_vocab(enc.config.vocab_size)
+    enc.tokenizer = build_wordpiece_tokenizer(vocab)
+    student = StudentModel.from_encoder(enc, "e5-small-v2-synthetic")
+    docs = synthetic_passages(vocab, n_docs)
+    emb = student.encode_documents(docs[:2048], batch_size=32)
+    assert emb.shape == (2048, enc.config.hidden_size)
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        emb = student.encode_documents(docs, batch_size=32)
+    dt = (time.perf_counter() - t0) / passes
+    stats = enc.last_encode_stats
+    t1 = time.perf_counter()
+    enc._tokenize_flat(["passage: " + d for d in docs[:8192]])
+    tok_rate = 8192 / (time.perf_counter() - t1)
+    return {
+        "value": round(n_docs / dt, 1),
+        "unit": "docs/s",
+        "workload": f"StudentModel.encode_documents over {n_docs} synthetic-vocabulary passages (Python str in, "
+                    f"NumPy out, batch_size=32 as the reference CLI passes it)",
+        "mean_tokens": round(stats["real_tokens"] / n_docs, 1),
+        "padding_overhead": round(stats["padding_overhead"], 4),
+        "tokenizer_alone_docs_per_s": round(tok_rate, 1),
+        "unit_norm_ok": bool(np.allclose(np.linalg.norm(emb, axis=1), 1.0, atol=1e-3)),
     }
 
 

@@ -29,6 +29,7 @@
 #include "common.h"
 
 #include <type_traits>
+#include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(
     const int* __restrict__ ids, const bf16x8* __restrict__ word, const bf16x8* __restrict__ pos,
     const bf16x8* __restrict__ type0, const float* __restrict__ gamma,
     const float* __restrict__ beta, int B, int S, int S_pad, int vocab, float eps,
-    bf16x8* __restrict__ out) {
+    bf16x8* __restrict__ out, const int* __restrict__ seg) {
   __shared__ bf16x8 tile[KSTEPS * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tt = blockIdx.x;
@@ -155,7 +156,15 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(
     const int r = wave * 8 + i;
     const int tok = tt * 32 + r;
     const int b = tok / S_pad, t = tok - b * S_pad;
-    const bool real = b < B && t < S;  // wave-uniform
+    bool real = b < B && t < S;  // wave-uniform
+    int tpos = t;
+    if (seg && real) {
+      // packed rows: the token's segment [lo, hi) inside its row; position ids restart per segment
+      const int sw = seg[(int64_t)b * S + t];
+      const int lo = sw & 0xffff, hi = (sw >> 16) & 0xffff;
+      real = hi > lo;
+      tpos = t - lo;
+    }
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.f;
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(
       int id = ids[(int64_t)b * S + t];
       id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
       const bf16x8 w = word[(int64_t)id * (H / 8) + lane];
-      const bf16x8 p = pos[(int64_t)t * (H / 8) + lane];
+      const bf16x8 p = pos[(int64_t)tpos * (H / 8) + lane];
       const bf16x8 ty = type0[lane];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = bf2f(w[j]) + bf2f(ty[j]) + bf2f(p[j]);
@@ -695,7 +704,8 @@ struct QkvAttnParams {
   const bf16x8* x;      // fragment-order [T_pad, 384]
   const bf16x8* wqkv;   // tiled [36][24][64]: tile h = Wq head h, 12 + h = Wk, 24 + h = Wv
   const float* bqkv;    // [1152]
-  const int* mask;      // [B, S]
+  const int* mask;      // [B, S] (unused when PACKED)
+  const int* seg;       // PACKED: [B, S] words lo | hi << 16: the token's segment [lo, hi) inside its row
   int B;
   int S;
   int nkt;              // S_pad / 32
@@ -738,8 +748,14 @@ __device__ unsigned long long g_probe_qa[16][8];
 // that order, waves 4-7 in the opposite order.  Wave w and w + 4 share a SIMD, so each SIMD
 // always has one wave on the matrix pipe and one on the vector pipe.  K / V fragments are
 // double-buffered in LDS (head k is written while head k-1 is read).
-template <bool TWO_TILES>
+//
+// PACKED (rows of <= 8 tiles): a row is a concatenation of whole sequences ("segments") and
+// attention is block-diagonal: a query sees the keys of its own segment only.  Per query tile the
+// key tiles outside the union of its queries' segments are skipped, tiles inside every query's
+// segment need no masking, the others get a per-element range test (key position - lo < length).
+template <bool TWO_TILES, bool PACKED = false>
 __global__ __launch_bounds__(512) void qkv_attention_kernel(QkvAttnParams p) {
+  static_assert(!(TWO_TILES && PACKED), "packed rows hold at most 8 token tiles");
   extern __shared__ __attribute__((aligned(16))) unsigned char qa_lds[];
   // T = spw * nkt token tiles live in the workgroup (<= 8, or nkt <= 16 in the TWO_TILES case)
   // [3 weight tiles: 72 KiB][2 x (K frags T*2 KiB, V frags T*2 KiB)][mask bias T*32 f32][bias 2 x 96 f32]
@@ -773,10 +789,14 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(QkvAttnParams p) {
   for (int i = tid; i < T * 32; i += 512) {  // at most one position per thread (T * 32 <= 512)
     const int si = i / (nkt * 32), pos = i - si * (nkt * 32);
     const int bi = bg * p.spw + si;
-    const bool on = bi < p.B && pos < S && p.mask[(int64_t)bi * S + pos] != 0;
-    mbias[i] = on ? 0.f : MASK_NEG;
-    if (on) atomicMax(&s_kmax[si], pos / 32 + 1);
-    else s_partial[i / 32] = 1;
+    if (PACKED) {
+      reinterpret_cast<int*>(mbias)[i] = (bi < p.B && pos < S) ? p.seg[(int64_t)bi * S + pos] : 0;
+    } else {
+      const bool on = bi < p.B && pos < S && p.mask[(int64_t)bi * S + pos] != 0;
+      mbias[i] = on ? 0.f : MASK_NEG;
+      if (on) atomicMax(&s_kmax[si], pos / 32 + 1);
+      else s_partial[i / 32] = 1;
+    }
   }
 
   // activations of this wave's token tile: resident for every head (single-tile case)
@@ -881,7 +901,23 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(QkvAttnParams p) {
     const bf16x8* vl = kl + T * 128;
     const float* mb_seq = mbias + sl * nkt * 32;
     const int* partial_seq = s_partial + sl * nkt;
-    const int kmax = s_kmax[sl];
+    int kmin = 0, kmax = s_kmax[sl];
+    int qlo = 0, qlen = 0;  // PACKED: this lane's query segment inside the row
+    if (PACKED) {
+      const int sw = reinterpret_cast<const int*>(mb_seq)[tq_w * 32 + r];
+      qlo = sw & 0xffff;
+      qlen = ((sw >> 16) & 0xffff) - qlo;
+      // key tiles covered by the segments of this tile's queries (padding queries have none)
+      int t_lo = qlen > 0 ? (qlo >> 5) : ATT_MAX_S, t_hi = qlen > 0 ? ((qlo + qlen + 31) >> 5) : 0;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        t_lo = min(t_lo, __shfl_xor(t_lo, o));
+        t_hi = max(t_hi, __shfl_xor(t_hi, o));
+      }
+      kmin = __builtin_amdgcn_readfirstlane(t_lo);
+      kmax = __builtin_amdgcn_readfirstlane(t_hi);
+      if (kmin > kmax) kmin = kmax = 0;
+    }
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       const int qt = (TWO_TILES ? wave : tq_w) + 8 * u;
@@ -909,7 +945,19 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(QkvAttnParams p) {
         // sc[t][4g + e] = score(key 32(kt + t) + 8g + 4h + e, query = lane), in log2 units
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          if (partial_seq[kt + t]) {  // only tiles with masked / padding keys pay for the bias
+          if (PACKED) {
+            // tiles lying inside every query's segment need no test (padding queries: anything goes)
+            const int k0 = (kt + t) * 32;
+            const bool inside = qlen <= 0 || (qlo <= k0 && qlo + qlen >= k0 + 32);
+            if (!__all(inside)) {
+              const unsigned base = (unsigned)(k0 + 4 * h - qlo);
+#pragma unroll
+              for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  if (base + (unsigned)(8 * g + e) >= (unsigned)qlen) sc[t][4 * g + e] = MASK_NEG;
+            }
+          } else if (partial_seq[kt + t]) {  // only tiles with masked / padding keys pay for the bias
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               const f32x4 mb = *reinterpret_cast<const f32x4*>(&mb_seq[(kt + t) * 32 + 8 * g + 4 * h]);
@@ -954,7 +1002,7 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(QkvAttnParams p) {
           o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl[((kt + t) * 2 + 1) * 64], pf[t][1], o, 0, 0, 0);
         }
       };
-      int kt = 0;
+      int kt = kmin;
       for (; kt + 2 <= kmax; kt += 2) tiles(kt, std::integral_constant<int, 2>{});
       if (kt < kmax) tiles(kt, std::integral_constant<int, 1>{});
       l = pair_sum(l);
@@ -1084,6 +1132,82 @@ __global__ __launch_bounds__(512) void pool_normalize_frag_kernel(const bf16x8* 
   }
 }
 
+// packed rows: one workgroup per SEQUENCE; table entry = { row, lo, hi, output row }
+__global__ __launch_bounds__(512) void pool_normalize_packed_kernel(const bf16x8* __restrict__ hidden,
+                                                                    const int4* __restrict__ table, int nkt,
+                                                                    int normalize, float* __restrict__ out) {
+  __shared__ float e_lds[H];
+  __shared__ float red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int4 ent = table[blockIdx.x];
+  const int row = ent.x, lo = ent.y, hi = ent.z;
+  float acc[3][8];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[a][j] = 0.f;
+  for (int kt = lo >> 5; kt < ((hi + 31) >> 5); ++kt) {
+    const int t = kt * 32 + r;
+    const float w = (t >= lo && t < hi) ? 1.0f : 0.0f;
+    const bf16x8* src = hidden + frag_base((int64_t)row * nkt + kt, 0, KSTEPS) + lane;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const bf16x8 v = src[(wave + 8 * a) * 64];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[a][j] = fmaf(w, bf2f(v[j]), acc[a][j]);
+    }
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[a][j] += __shfl_xor(acc[a][j], o);
+  }
+  const float n = fmaxf((float)(hi - lo), 1e-9f);
+  if (r == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e_lds[16 * (wave + 8 * a) + 8 * h + j] = acc[a][j] / n;
+  }
+  __syncthreads();
+  float ss = 0.f;
+  if (tid < H) ss = e_lds[tid] * e_lds[tid];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  if (lane == 0) red[wave] = ss;
+  __syncthreads();
+  if (tid < H) {
+    float e = e_lds[tid];
+    if (normalize) {
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < 6; ++w) tot += red[w];
+      e /= fmaxf(sqrtf(tot), 1e-12f);
+    }
+    out[(int64_t)ent.w * H + tid] = e;
+  }
+}
+
+// flat token stream + per-sequence placement -> padded packed rows: ids [R, C] and segment words
+// [R, C] (lo | hi << 16), both zero-filled beforehand.  One workgroup per sequence.
+__global__ __launch_bounds__(256) void pack_tokens_kernel(const int* __restrict__ flat_ids,
+                                                          const int* __restrict__ cu_seqlens,
+                                                          const int4* __restrict__ table, int C,
+                                                          int* __restrict__ ids, int* __restrict__ seg) {
+  const int4 ent = table[blockIdx.x];
+  const int src0 = cu_seqlens[blockIdx.x];
+  const int len = ent.z - ent.y;
+  const int word = ent.y | (ent.z << 16);
+  for (int i = threadIdx.x; i < len; i += 256) {
+    const int64_t dst = (int64_t)ent.x * C + ent.y + i;
+    ids[dst] = flat_ids[src0 + i];
+    seg[dst] = word;
+  }
+}
+
 __global__ __launch_bounds__(256) void untile_hidden_kernel(const __bf16* __restrict__ frag, int B, int S,
                                                             int nkt, __bf16* __restrict__ rows) {
   const int64_t total = (int64_t)B * S * H;
@@ -1146,13 +1270,13 @@ int check_cfg(const sskd_encoder_config* cfg, const sskd_encoder_weights* w, int
 // runs embeddings + all layers; returns the (fragment-order) buffer holding the final hidden states
 int run_layers(const sskd_encoder_config* cfg, const sskd_encoder_weights* w, const int32_t* d_ids,
                const int32_t* d_mask, int B, int S, const Workspace& ws, hipStream_t st,
-               __bf16** final_hidden) {
+               __bf16** final_hidden, const int32_t* d_seg = nullptr) {
   const int Sp = s_pad_of(S), nkt = Sp / 32;
   const int Tpad = (int)t_pad_of(B, S);
   hipLaunchKernelGGL(embed_ln_kernel, dim3(Tpad / 32), dim3(256), 0, st, d_ids,
                      static_cast<const bf16x8*>(w->word_emb), static_cast<const bf16x8*>(w->pos_emb),
                      static_cast<const bf16x8*>(w->type_emb), w->emb_ln_g, w->emb_ln_b, B, S, Sp,
-                     cfg->vocab_size, cfg->layer_norm_eps, reinterpret_cast<bf16x8*>(ws.xa));
+                     cfg->vocab_size, cfg->layer_norm_eps, reinterpret_cast<bf16x8*>(ws.xa), d_seg);
   int rc = sskd::check_launch("embed_ln_kernel");
   if (rc != SSKD_OK) return rc;
 
@@ -1168,6 +1292,7 @@ int run_layers(const sskd_encoder_config* cfg, const sskd_encoder_weights* w, co
     qa.wqkv = static_cast<const bf16x8*>(lw.wqkv);
     qa.bqkv = lw.bqkv;
     qa.mask = d_mask;
+    qa.seg = d_seg;
     qa.B = B;
     qa.S = S;
     qa.nkt = nkt;
@@ -1191,7 +1316,8 @@ int run_layers(const sskd_encoder_config* cfg, const sskd_encoder_weights* w, co
     o.beta = lw.ln1_b;
     o.eps = cfg->layer_norm_eps;
     o.out = x1;
-    auto qa_kernel = nkt > 8 ? qkv_attention_kernel<true> : qkv_attention_kernel<false>;
+    auto qa_kernel = nkt > 8 ? qkv_attention_kernel<true, false>
+                             : (d_seg ? qkv_attention_kernel<false, true> : qkv_attention_kernel<false, false>);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(qa_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)qa_lds_bytes);
     hipLaunchKernelGGL(qa_kernel, dim3(qa_rows * (NH / qa.hpw)), dim3(512), qa_lds_bytes, st, qa);
@@ -1286,6 +1412,83 @@ int sskd_encoder_forward(const sskd_encoder_config* cfg, const sskd_encoder_weig
                      reinterpret_cast<const bf16x8*>(fin), d_mask, S, s_pad_of(S) / 32, normalize,
                      d_out);
   return sskd::check_launch("pool_normalize_frag_kernel");
+}
+
+
+// ---- sequence packing ("cu_seqlens" varlen): whole sequences concatenated into rows of C tokens ----
+
+int sskd_pack_plan(const int32_t* lengths, int n_seq, int capacity, int32_t* table, int* n_rows) {
+  SSKD_REQUIRE(n_seq >= 0 && lengths && table && n_rows, "pack_plan: null pointer / negative count");
+  SSKD_REQUIRE(capacity >= 32 && capacity <= 256 && capacity % 32 == 0,
+               "pack_plan: capacity=%d must be a multiple of 32 in [32, 256]", capacity);
+  // best-fit decreasing: sequences by decreasing length (counting sort), each into the row whose
+  // free space is the smallest that still fits (rows bucketed by free space), else a new row
+  std::vector<int> order(n_seq), start(capacity + 2, 0);
+  for (int i = 0; i < n_seq; ++i) {
+    SSKD_REQUIRE(lengths[i] >= 1 && lengths[i] <= capacity, "pack_plan: length[%d]=%d outside [1, %d]", i,
+                 lengths[i], capacity);
+    ++start[capacity - lengths[i] + 1];
+  }
+  for (int f = 0; f <= capacity; ++f) start[f + 1] += start[f];
+  for (int i = 0; i < n_seq; ++i) order[start[capacity - lengths[i]]++] = i;
+  std::vector<std::vector<int>> by_free(capacity + 1);
+  int rows = 0;
+  for (int oi = 0; oi < n_seq; ++oi) {
+    const int i = order[oi], len = lengths[i];
+    int f = len;
+    while (f <= capacity && by_free[f].empty()) ++f;
+    int row;
+    if (f > capacity) {
+      row = rows++;
+      f = capacity;
+    } else {
+      row = by_free[f].back();
+      by_free[f].pop_back();
+    }
+    table[4 * i + 0] = row;
+    table[4 * i + 1] = capacity - f;
+    table[4 * i + 2] = capacity - f + len;
+    table[4 * i + 3] = i;
+    if (f - len > 0) by_free[f - len].push_back(row);
+  }
+  *n_rows = rows;
+  return SSKD_OK;
+}
+
+int sskd_pack_tokens(const int32_t* d_flat_ids, const int32_t* d_cu_seqlens, const int32_t* d_table,
+                     int n_seq, int n_rows, int capacity, int32_t* d_ids, int32_t* d_seg, void* stream) {
+  SSKD_REQUIRE(n_seq >= 0 && n_rows >= 0 && capacity >= 32 && capacity % 32 == 0, "pack_tokens: bad shape");
+  if (n_rows == 0) return SSKD_OK;
+  SSKD_REQUIRE(d_ids && d_seg, "pack_tokens: null output");
+  hipStream_t st = sskd::as_stream(stream);
+  const size_t bytes = (size_t)n_rows * capacity * sizeof(int32_t);
+  if (hipMemsetAsync(d_ids, 0, bytes, st) != hipSuccess || hipMemsetAsync(d_seg, 0, bytes, st) != hipSuccess)
+    return sskd::fail(SSKD_ERR_HIP, "pack_tokens: hipMemsetAsync failed");
+  if (n_seq == 0) return SSKD_OK;
+  SSKD_REQUIRE(d_flat_ids && d_cu_seqlens && d_table, "pack_tokens: null input");
+  hipLaunchKernelGGL(pack_tokens_kernel, dim3(n_seq), dim3(256), 0, st, d_flat_ids, d_cu_seqlens,
+                     reinterpret_cast<const int4*>(d_table), capacity, d_ids, d_seg);
+  return sskd::check_launch("pack_tokens_kernel");
+}
+
+int sskd_encoder_forward_packed(const sskd_encoder_config* cfg, const sskd_encoder_weights* w,
+                                const int32_t* d_ids, const int32_t* d_seg, int n_rows, int capacity,
+                                const int32_t* d_table, int n_seq, int normalize, float* d_out,
+                                void* d_workspace, size_t workspace_bytes, void* stream) {
+  SSKD_REQUIRE(capacity >= 32 && capacity <= 256 && capacity % 32 == 0,
+               "encoder_forward_packed: capacity=%d must be a multiple of 32 in [32, 256]", capacity);
+  Workspace ws{};
+  int rc = prepare(cfg, w, n_rows, capacity, d_workspace, workspace_bytes, &ws);
+  if (rc != SSKD_OK || n_rows == 0 || n_seq == 0) return rc;
+  SSKD_REQUIRE(n_seq > 0 && d_ids && d_seg && d_table && d_out, "encoder_forward_packed: null pointer");
+  hipStream_t st = sskd::as_stream(stream);
+  __bf16* fin = nullptr;
+  rc = run_layers(cfg, w, d_ids, nullptr, n_rows, capacity, ws, st, &fin, d_seg);
+  if (rc != SSKD_OK) return rc;
+  hipLaunchKernelGGL(pool_normalize_packed_kernel, dim3(n_seq), dim3(512), 0, st,
+                     reinterpret_cast<const bf16x8*>(fin), reinterpret_cast<const int4*>(d_table),
+                     capacity / 32, normalize, d_out);
+  return sskd::check_launch("pool_normalize_packed_kernel");
 }
 
 }  // extern "C"

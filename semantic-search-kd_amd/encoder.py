@@ -10,7 +10,11 @@ There is no CPU path: without an MI355X and the built library, construction fail
 """
 from __future__ import annotations
 
+import ctypes
+import itertools
 import json
+import os
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 from typing import Dict, List, Optional, Sequence, Union
 
@@ -21,6 +25,98 @@ from . import _native
 from .weights import BertConfig, DeviceWeights, load_config, load_state_dict, synthetic_state_dict
 
 CLS_ID, SEP_ID, PAD_ID = 101, 102, 0
+
+ROW_CAPACITY = 256          # tokens per packed row (8 token tiles: one attention workgroup)
+LAUNCH_TOKENS = 512 * 256   # padded tokens per forward launch (the benchmarked batch 512 x 256 shape)
+TOKENIZE_CHUNK = 8192       # texts tokenised per background task while the GPU encodes the previous chunk
+
+
+class _Staging:
+    """Pinned host buffer + device twin for one launch's inputs (flat ids | cu_seqlens | plan table),
+    moved with ONE asynchronous copy.  A small ring of these lets the host fill launch i + 1 while
+    the copy of launch i is still in flight."""
+
+    def __init__(self, device, words: int):
+        self.host = torch.empty(words, dtype=torch.int32).pin_memory()
+        self.dev = torch.empty(words, dtype=torch.int32, device=device)
+        self.np = self.host.numpy()
+        self.done = torch.cuda.Event()
+        self.used = False
+
+
+class NativeWordPiece:
+    """The C++ WordPiece tokenizer of the C-ABI library (``sskd_tokenizer_*``), built from a
+    ``tokenizers.Tokenizer`` when - and only when - that tokenizer is the uncased BERT recipe it
+    implements (BertNormalizer lowercase, BertPreTokenizer, WordPiece "##", [CLS] $A [SEP])."""
+
+    def __init__(self, vocab_tokens: Sequence[str], max_chars_per_word: int = 100):
+        lib = _native.load()
+        blob = "\n".join(vocab_tokens).encode("utf-8")
+        self._handle = ctypes.c_void_p()
+        _native.check(lib.sskd_tokenizer_create(blob, len(blob), ctypes.byref(self._handle)))
+        self._lib = lib
+        self.threads = max(1, min(16, os.cpu_count() or 1))
+        if max_chars_per_word != 100:
+            raise ValueError("the native tokenizer implements max_input_chars_per_word = 100")
+
+    @classmethod
+    def from_hf(cls, tok) -> Optional["NativeWordPiece"]:
+        try:
+            spec = json.loads(tok.to_str())
+            model, norm = spec.get("model") or {}, spec.get("normalizer") or {}
+            pre, post = spec.get("pre_tokenizer") or {}, spec.get("post_processor") or {}
+            ok = (
+                model.get("type") == "WordPiece"
+                and model.get("continuing_subword_prefix", "##") == "##"
+                and model.get("unk_token") == "[UNK]"
+                and model.get("max_input_chars_per_word", 100) == 100
+                and norm.get("type") == "BertNormalizer"
+                and norm.get("lowercase", True) is True
+                and norm.get("clean_text", True) is True
+                and pre.get("type") == "BertPreTokenizer"
+                and post.get("type") in ("TemplateProcessing", "BertProcessing")
+                and not spec.get("added_tokens_need_matching")
+            )
+            if not ok:
+                return None
+            vocab = model["vocab"]
+            toks = [None] * len(vocab)
+            for t, i in vocab.items():
+                if not 0 <= i < len(toks) or toks[i] is not None or "\n" in t:
+                    return None
+                toks[i] = t
+            return cls(toks)
+        except Exception:
+            return None
+
+    def encode_flat(self, texts: Sequence[str], max_len: int):
+        """-> (flat int32 ids, lengths int32, needs_unicode bool[n]) or None when the texts cannot be
+        NUL-joined (a text contains NUL)."""
+        n = len(texts)
+        blob = "\x00".join(texts).encode("utf-8")
+        seps = np.flatnonzero(np.frombuffer(blob, np.uint8) == 0)
+        if seps.size != max(n - 1, 0):
+            return None
+        offsets = np.empty(n + 1, np.int64)
+        offsets[0] = 0
+        offsets[1:n] = seps + 1
+        offsets[n] = len(blob)
+        cap = len(blob) + 2 * n + 16  # every id consumes at least one input byte, plus [CLS] / [SEP]
+        ids = np.empty(cap, np.int32)
+        lengths = np.empty(n, np.int32)
+        flags = np.empty(n, np.uint8)
+        total = ctypes.c_int64(0)
+        _native.check(self._lib.sskd_tokenizer_encode(
+            self._handle, blob, offsets.ctypes.data, n, max_len, self.threads, ids.ctypes.data, cap,
+            lengths.ctypes.data, flags.ctypes.data, ctypes.byref(total)))
+        return ids[: total.value], lengths, flags.astype(bool)
+
+    def __del__(self):
+        try:
+            if self._handle:
+                self._lib.sskd_tokenizer_destroy(self._handle)
+        except Exception:
+            pass
 
 
 class Mi355xSentenceEncoder:
@@ -52,12 +148,31 @@ class Mi355xSentenceEncoder:
             state_dict = load_state_dict(model_dir)
         self.config = config or BertConfig()
         self.weights = DeviceWeights(self.config, state_dict, self.device)
+        self._tokenizer = None
+        self._native_tok: Optional[NativeWordPiece] = None
         self.tokenizer = tokenizer if tokenizer is not None else _load_tokenizer(model_dir)
         st_max = _read_st_max_len(model_dir)
         self.max_seq_length = int(
             max_seq_length or st_max or min(512, self.config.max_position_embeddings)
         )
         self._workspace: Optional[torch.Tensor] = None
+        self._staging: List[_Staging] = []
+        self._stage_next = 0
+        self._rows_ids: Optional[torch.Tensor] = None
+        self._rows_seg: Optional[torch.Tensor] = None
+        self._tok_pool: Optional[ThreadPoolExecutor] = None
+        self.last_encode_stats: Dict[str, float] = {}
+
+    @property
+    def tokenizer(self):
+        return self._tokenizer
+
+    @tokenizer.setter
+    def tokenizer(self, tok) -> None:
+        """The ``tokenizers.Tokenizer`` (always the reference for text -> ids); when it is the uncased
+        BERT recipe, ASCII texts are tokenised by the multi-threaded C++ twin instead."""
+        self._tokenizer = tok
+        self._native_tok = NativeWordPiece.from_hf(tok) if tok is not None else None
 
     # ----------------------------------------------------------- constructors
     @classmethod
@@ -135,6 +250,125 @@ class Mi355xSentenceEncoder:
         )
         return out
 
+
+    # ------------------------------------------------------------ packed varlen path
+    def _stage(self, words: int) -> _Staging:
+        if not self._staging or self._staging[0].host.numel() < words:
+            size = max(words, LAUNCH_TOKENS + 5 * (LAUNCH_TOKENS // 8) + 64)
+            self._staging = [_Staging(self.device, size) for _ in range(3)]
+            self._stage_next = 0
+        st = self._staging[self._stage_next]
+        self._stage_next = (self._stage_next + 1) % len(self._staging)
+        if st.used:
+            st.done.synchronize()  # its previous copy has been consumed by the GPU
+        return st
+
+    def encode_ragged(self, flat_ids: np.ndarray, lengths: np.ndarray, normalize: bool = True,
+                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Varlen forward: ``flat_ids`` holds the sequences back to back (int32), ``lengths[i]`` tokens each
+        (1 .. ROW_CAPACITY).  Whole sequences are packed into rows of ROW_CAPACITY tokens
+        (``sskd_pack_plan``: best-fit decreasing, so only row tails are padding), attention is
+        block-diagonal per sequence, and the pooled embedding of sequence i lands in ``out[i]``:
+        no length sorting, no per-batch padding, no scatter.  Launches are cut by a token budget
+        (LAUNCH_TOKENS), not by a caller batch size.  Enqueued on the current stream."""
+        lib = _native.load()
+        lengths = np.ascontiguousarray(lengths, np.int32)
+        flat_ids = np.ascontiguousarray(flat_ids, np.int32)
+        n = int(lengths.shape[0])
+        if out is None:
+            out = torch.empty((n, self.config.hidden_size), dtype=torch.float32, device=self.device)
+        if n == 0:
+            return out
+        if int(lengths.min()) < 1 or int(lengths.max()) > ROW_CAPACITY:
+            raise ValueError(f"encode_ragged: lengths must lie in [1, {ROW_CAPACITY}]")
+        cu = np.zeros(n + 1, np.int64)
+        np.cumsum(lengths, out=cu[1:])
+        if int(cu[-1]) != flat_ids.shape[0]:
+            raise ValueError("encode_ragged: flat_ids does not hold sum(lengths) tokens")
+        stream = int(torch.cuda.current_stream(self.device).cuda_stream)
+        budget = int(LAUNCH_TOKENS * 0.97)
+        padded_tokens = 0
+        s0 = 0
+        while s0 < n:
+            s1 = int(np.searchsorted(cu, cu[s0] + budget, side="right")) - 1
+            s1 = min(max(s1, s0 + 1), n)
+            m, t0, t1 = s1 - s0, int(cu[s0]), int(cu[s1])
+            total = t1 - t0
+            cap = ROW_CAPACITY if total >= ROW_CAPACITY else -(-total // 32) * 32
+            st = self._stage(total + (m + 1) + 4 * m)
+            a = st.np
+            a[:total] = flat_ids[t0:t1]
+            a[total : total + m + 1] = cu[s0 : s1 + 1] - t0
+            table = a[total + m + 1 : total + m + 1 + 4 * m]
+            n_rows = ctypes.c_int(0)
+            _native.check(lib.sskd_pack_plan(lengths[s0:s1].ctypes.data, m, cap, table.ctypes.data, n_rows))
+            rows = n_rows.value
+            words = total + (m + 1) + 4 * m
+            st.dev[:words].copy_(st.host[:words], non_blocking=True)
+            st.done.record(torch.cuda.current_stream(self.device))
+            st.used = True
+            need_rows = rows * cap
+            if self._rows_ids is None or self._rows_ids.numel() < need_rows:
+                size = max(need_rows, LAUNCH_TOKENS + 16 * ROW_CAPACITY)
+                self._rows_ids = torch.empty(size, dtype=torch.int32, device=self.device)
+                self._rows_seg = torch.empty(size, dtype=torch.int32, device=self.device)
+            base = st.dev.data_ptr()
+            d_cu, d_table = base + 4 * total, base + 4 * (total + m + 1)
+            _native.check(lib.sskd_pack_tokens(base, d_cu, d_table, m, rows, cap, self._rows_ids.data_ptr(),
+                                               self._rows_seg.data_ptr(), stream))
+            need = int(lib.sskd_encoder_workspace_bytes(self.weights.cstruct_cfg, rows, cap))
+            if self._workspace is None or self._workspace.numel() < need:
+                self._workspace = None
+                self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+            _native.check(
+                lib.sskd_encoder_forward_packed(
+                    self.weights.cstruct_cfg, self.weights.struct, self._rows_ids.data_ptr(), self._rows_seg.data_ptr(),
+                    rows, cap, d_table, m, int(bool(normalize)), out[s0:].data_ptr(),
+                    self._workspace.data_ptr(), self._workspace.numel(), stream,
+                )
+            )
+            padded_tokens += rows * cap
+            s0 = s1
+        self.last_encode_stats = {"real_tokens": float(cu[-1]), "padded_tokens": float(padded_tokens),
+                                  "padding_overhead": padded_tokens / float(cu[-1]) - 1.0}
+        return out
+
+    def _tokenize_flat(self, texts: Sequence[str]):
+        """WordPiece ids of ``texts`` as one flat int32 stream + lengths (truncated to max_seq_length,
+        keeping the closing [SEP])."""
+        if self.tokenizer is None:
+            raise RuntimeError(
+                "no tokenizer: the model directory has neither tokenizer.json nor vocab.txt "
+                "(use encode_token_ids / encode_ragged for pre-tokenised input)"
+            )
+        mx = self.max_seq_length
+        fast = getattr(self.tokenizer, "encode_batch_fast", None) or self.tokenizer.encode_batch
+        if self._native_tok is not None and len(texts):
+            res = self._native_tok.encode_flat(texts, mx)
+            if res is not None:
+                flat, lengths, uni = res
+                if not uni.any():
+                    return flat, lengths
+                # texts with non-ASCII characters: the Unicode-complete tokenizer, spliced back in place
+                idx = np.flatnonzero(uni)
+                pieces = np.split(flat, np.cumsum(lengths)[:-1])
+                for i, e in zip(idx, fast([texts[j] for j in idx])):
+                    r = e.ids if len(e.ids) <= mx else e.ids[: mx - 1] + e.ids[-1:]
+                    pieces[i] = np.asarray(r or [PAD_ID], np.int32)
+                    lengths[i] = len(pieces[i])
+                return np.concatenate(pieces), lengths
+        encs = fast(list(texts))
+        rows = [e.ids for e in encs]
+        lengths = np.fromiter((len(r) for r in rows), np.int32, count=len(rows))
+        if len(rows) and int(lengths.max()) > mx:
+            rows = [r if len(r) <= mx else r[: mx - 1] + r[-1:] for r in rows]
+            lengths = np.minimum(lengths, mx)
+        if len(rows) and int(lengths.min()) < 1:  # a tokenizer without a [CLS] .. [SEP] template
+            rows = [r if r else [PAD_ID] for r in rows]
+            lengths = np.maximum(lengths, 1)
+        flat = np.fromiter(itertools.chain.from_iterable(rows), np.int32, count=int(lengths.sum()))
+        return flat, lengths
+
     def hidden_states(self, input_ids, attention_mask=None) -> torch.Tensor:
         """bf16 ``[B, S, 384]`` output of the last encoder layer (test hook)."""
         lib = _native.load()
@@ -163,26 +397,59 @@ class Mi355xSentenceEncoder:
         device: Optional[str] = None,
         **_ignored,
     ):
-        """Same contract as ``SentenceTransformer.encode``: sort by length (longest first),
-        batch, pad per batch, forward, restore the input order.  The e5 pipeline ends in a
-        ``Normalize`` module, so embeddings are unit-norm whatever ``normalize_embeddings`` says."""
-        del show_progress_bar, device, normalize_embeddings
+        """Same contract as ``SentenceTransformer.encode`` (str or list in, [n, 384] out, input order
+        kept); the e5 pipeline ends in a ``Normalize`` module, so embeddings are unit-norm whatever
+        ``normalize_embeddings`` says.  Where sentence-transformers sorts by length and pads every
+        batch of ``batch_size`` texts to its longest member, this path packs whole sequences into
+        256-token rows (``encode_ragged``) and cuts launches by a token budget: ``batch_size`` (the
+        reference CLI default is 32) does not shape the GPU work.  Texts are tokenised in chunks on a
+        background thread (the Rust tokenizer releases the GIL) while the GPU encodes the previous
+        chunk.  Texts longer than one row (> 256 tokens) take the padded ``encode_token_ids`` path."""
+        del show_progress_bar, device, normalize_embeddings, batch_size
         single = isinstance(sentences, str)
         texts = [sentences] if single else list(sentences)
         n = len(texts)
         out = torch.empty((n, self.config.hidden_size), dtype=torch.float32, device=self.device)
+        real = padded = 0.0
         if n:
-            tok = self.tokenize(texts)
-            lengths = tok["attention_mask"].sum(axis=1)
-            order = np.argsort(-lengths, kind="stable")
+            if self._tok_pool is None:
+                self._tok_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="sskd-tokenize")
+            bounds = list(range(0, n, TOKENIZE_CHUNK)) + [n]
+            pending = self._tok_pool.submit(self._tokenize_flat, texts[bounds[0] : bounds[1]])
             with torch.cuda.device(self.device):
-                for lo in range(0, n, batch_size):
-                    idx = order[lo : lo + batch_size]
-                    width = max(int(lengths[idx].max()), 1)
-                    emb = self.encode_token_ids(
-                        tok["input_ids"][idx, :width], tok["attention_mask"][idx, :width], normalize=True
-                    )
-                    out[torch.from_numpy(idx).to(self.device)] = emb
+                for ci in range(len(bounds) - 1):
+                    flat, lengths = pending.result()
+                    if ci + 2 < len(bounds):
+                        pending = self._tok_pool.submit(self._tokenize_flat, texts[bounds[ci + 1] : bounds[ci + 2]])
+                    lo = bounds[ci]
+                    long_rows = np.nonzero(lengths > ROW_CAPACITY)[0]
+                    if long_rows.size == 0:
+                        self.encode_ragged(flat, lengths, normalize=True, out=out[lo : bounds[ci + 1]])
+                        real += self.last_encode_stats["real_tokens"]
+                        padded += self.last_encode_stats["padded_tokens"]
+                        continue
+                    cu = np.zeros(len(lengths) + 1, np.int64)
+                    np.cumsum(lengths, out=cu[1:])
+                    short = np.nonzero(lengths <= ROW_CAPACITY)[0]
+                    if short.size:
+                        keep = np.concatenate([flat[cu[i] : cu[i + 1]] for i in short])
+                        emb = self.encode_ragged(keep, lengths[short], normalize=True)
+                        out[torch.from_numpy(lo + short).to(self.device)] = emb
+                        real += self.last_encode_stats["real_tokens"]
+                        padded += self.last_encode_stats["padded_tokens"]
+                    for i0 in range(0, long_rows.size, 64):
+                        idx = long_rows[i0 : i0 + 64]
+                        width = int(lengths[idx].max())
+                        ids = np.full((idx.size, width), PAD_ID, np.int32)
+                        mask = np.zeros((idx.size, width), np.int32)
+                        for j, i in enumerate(idx):
+                            ids[j, : lengths[i]] = flat[cu[i] : cu[i + 1]]
+                            mask[j, : lengths[i]] = 1
+                        out[torch.from_numpy(lo + idx).to(self.device)] = self.encode_token_ids(ids, mask, normalize=True)
+                        real += float(lengths[idx].sum())
+                        padded += float(idx.size * (-(-width // 32) * 32))
+        self.last_encode_stats = {"real_tokens": real, "padded_tokens": padded,
+                                  "padding_overhead": (padded / real - 1.0) if real else 0.0}
         if convert_to_tensor and not convert_to_numpy:
             return out[0] if single else out
         arr = out.cpu().numpy()
@@ -190,6 +457,10 @@ class Mi355xSentenceEncoder:
 
     def cleanup(self) -> None:
         self._workspace = None
+        self._staging, self._rows_ids, self._rows_seg = [], None, None
+        if self._tok_pool is not None:
+            self._tok_pool.shutdown(wait=True)
+            self._tok_pool = None
 
 
 # ---------------------------------------------------------------------- helpers

@@ -48,6 +48,19 @@ class StudentModel:
         self.embedding_dim = self.model.get_sentence_embedding_dimension()
         self.max_length = getattr(self.model, "max_seq_length", 512)
 
+    @classmethod
+    def from_encoder(cls, encoder, model_name: str, prefix_mode: str = "auto") -> "StudentModel":
+        """Wrap an already constructed sentence encoder (synthetic weights in benchmarks / tests; the
+        reference's tests inject a mock the same way: tests/test_student_model.py:12-19)."""
+        self = cls.__new__(cls)
+        self.model_name = model_name
+        self.device = str(encoder.device)
+        self.prefix_mode = prefix_mode
+        self.model = encoder
+        self.embedding_dim = encoder.get_sentence_embedding_dimension()
+        self.max_length = getattr(encoder, "max_seq_length", 512)
+        return self
+
     # ------------------------------------------------------------------ encode
     @property
     def is_e5(self) -> bool:

@@ -232,7 +232,9 @@ def test_text_path_and_student_model(gpu, tmp_path):
     # single string in -> [1, 384] out through StudentModel.encode (wrapped into a list)
     one = student.encode("hello world")
     assert one.shape == (1, 384)
-    np.testing.assert_allclose(one[0], emb[1], atol=1e-5)  # batch-size / order independence
+    # batch-mate independence: the text path packs sequences into shared rows, so only the grouping of
+    # keys into 32-key tiles differs between the two calls (bf16 tolerance of SURVEY.md section 8f: 1e-2)
+    np.testing.assert_allclose(one[0], emb[1], atol=2e-3)
     # E5 prefixes (tests/test_student_model.py:72-102)
     q = student.encode_queries("hello world")
     q_manual = student.encode(["query: hello world"])

@@ -195,3 +195,41 @@ def test_bench_self_launches_ranks_from_a_bare_shell():
     bad = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--launch-check", "--steps", "x"],
                          env=env, capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0
+
+
+def test_native_wordpiece_equals_tokenizers_library():
+    """The C++ host tokenizer (sskd_tokenizer_*) reproduces the `tokenizers` library - the engine
+    behind the reference's SentenceTransformer.encode - id for id on ASCII text, and FLAGS every text
+    with non-ASCII characters instead of approximating it."""
+    import numpy as np
+
+    from semantic_search_kd_amd.bench_support import synthetic_passages, synthetic_vocab
+    from semantic_search_kd_amd.encoder import NativeWordPiece, build_wordpiece_tokenizer
+
+    vocab = synthetic_vocab()
+    tok = build_wordpiece_tokenizer(vocab)
+    nt = NativeWordPiece.from_hf(tok)
+    assert nt is not None
+    texts = ["passage: " + d for d in synthetic_passages(vocab, 400, seed=9)]
+    texts += ["", "   ", "Hello, World!! what's   up\t(with) THIS_thing?", "x" + "y" * 120 + " end",
+              "bell\x07char and\x7fdel", "a.b-c $5.00 #tag @you [brackets] {braces} `tick` ~tilde^", "UPPER lower MiXeD",
+              "tab\tnew\nline\rreturn", "query: how does semantic search work?", "123 4567 89.0", "[CLS] literal [SEP]"]
+    rng = np.random.default_rng(0)
+    alphabet = np.array(list("abcdefghijklmnopqrstuvwxyzABCXYZ0123456789     .,;:!?'\"()-_/\\@#$%&*+=<>[]{}|~^`\t\n"))
+    texts += ["".join(rng.choice(alphabet, size=int(rng.integers(0, 300)))) for _ in range(300)]
+    texts += ["café naïve", "日本語 text", "emoji \U0001F600 here"]
+    for max_len in (512, 16):
+        flat, lengths, uni = nt.encode_flat(texts, max_len)
+        assert uni.tolist() == [any(ord(c) > 127 for c in t) for t in texts]
+        cu = np.concatenate([[0], np.cumsum(lengths)])
+        for i, e in enumerate(tok.encode_batch(texts)):
+            if uni[i]:
+                assert lengths[i] == 0
+                continue
+            want = e.ids if len(e.ids) <= max_len else e.ids[: max_len - 1] + e.ids[-1:]
+            assert flat[cu[i] : cu[i + 1]].tolist() == want, texts[i]
+    assert nt.encode_flat(["a\x00b", "c"], 512) is None  # NUL inside a text: caller uses the library path
+    # a tokenizer that is not the uncased BERT recipe is never replaced
+    from tokenizers import Tokenizer, models
+
+    assert NativeWordPiece.from_hf(Tokenizer(models.WordPiece({"[UNK]": 0}, unk_token="[UNK]"))) is None
