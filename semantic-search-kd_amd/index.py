@@ -334,6 +334,17 @@ class FAISSIndexBuilder:
         return self._search_numpy(query_emb, k, normalize_queries=None)
 
     # -------------------------------------------------------------- persistence
+    def reconstruct(self, rows: Sequence[int]) -> np.ndarray:
+        """Stored vectors of the given local rows (``faiss.Index.reconstruct`` for a list), host fp32."""
+        lib = _native.load()
+        rows = [int(r) for r in rows]
+        out = torch.empty((len(rows), self.embedding_dim), dtype=torch.float32, device=self.device)
+        for j, r in enumerate(rows):
+            if not 0 <= r < self._n:
+                raise IndexError(f"row {r} outside [0, {self._n})")
+            _native.check(lib.sskd_index_get_rows(self._tiled.data_ptr(), r, 1, out[j].data_ptr(), _stream(self.device)))
+        return out.cpu().numpy()
+
     def to_numpy(self) -> np.ndarray:
         """Row-major copy of the stored vectors (host)."""
         lib = _native.load()

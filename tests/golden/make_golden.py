@@ -227,6 +227,70 @@ def make_search_ref():
         np.savez_compressed(HERE / f"search_ref_{tag}.npz", **store)
 
 
+class HashedEmbeddingStudent:
+    """Deterministic stand-in student for miner fixtures: the embedding of a text is a unit vector
+    seeded by crc32(text) (+ the e5 role prefix the real StudentModel would prepend); similarity in
+    float64 so that batched and per-query products agree to the bit."""
+
+    dim = 64
+
+    def _emb(self, texts):
+        import zlib
+
+        out = np.empty((len(texts), self.dim), np.float32)
+        for i, t in enumerate(texts):
+            g = np.random.Generator(np.random.PCG64(zlib.crc32(t.encode("utf-8"))))
+            v = g.standard_normal(self.dim)
+            out[i] = (v / np.linalg.norm(v)).astype(np.float32)
+        return out
+
+    def encode_queries(self, queries, **kw):
+        return self._emb(["query: " + q for q in ([queries] if isinstance(queries, str) else queries)])
+
+    def encode_documents(self, docs, **kw):
+        return self._emb(["passage: " + d for d in ([docs] if isinstance(docs, str) else docs)])
+
+    def compute_similarity(self, q, d):
+        return (np.asarray(q, np.float64) @ np.asarray(d, np.float64).T).astype(np.float32)
+
+
+def ance_case():
+    """Inputs of the ANCE fixture: topical word pools so that some candidates land inside the margin."""
+    rng = np.random.default_rng(12)
+    words = [f"w{i}" for i in range(40)]
+    docs = {f"d{i}": " ".join(rng.choice(words, size=int(rng.integers(3, 9)))) for i in range(60)}
+    docs["d7"] = ""  # empty text
+    queries = [" ".join(rng.choice(words, size=4)) for _ in range(12)]
+    positives = [[f"d{int(j)}" for j in rng.choice(60, size=int(rng.integers(0, 3)), replace=False)] for _ in queries]
+    candidates = [[f"d{int(j)}" for j in rng.choice(60, size=int(rng.integers(0, 25)), replace=False)] for _ in queries]
+    candidates[3] = candidates[3] + ["missing-id"]  # not in the text table -> "" (miners.py:219)
+    return queries, positives, candidates, docs
+
+
+def make_ance():
+    """Hard negatives chosen by the REFERENCE'S OWN ``ANCEMiner.mine`` (src/mining/miners.py:184-253)
+    for a deterministic stand-in student.  ``rank_bm25`` (used by the sibling BM25 classes of that
+    module, never by ANCEMiner) is absent here: an empty placeholder module lets the import through."""
+    import json
+    import types
+
+    _register_reference_stubs()
+    if "rank_bm25" not in sys.modules:
+        ph = types.ModuleType("rank_bm25")
+        ph.BM25Okapi = type("BM25Okapi", (), {})
+        sys.modules["rank_bm25"] = ph
+    from src.mining.miners import ANCEMiner as RefMiner
+
+    queries, positives, candidates, docs = ance_case()
+    out = {}
+    for margin in (0.1, 0.3, 0.0):
+        for top_k in (5, 2):
+            got = RefMiner(HashedEmbeddingStudent(), margin=margin).mine(queries, positives, candidates, docs, docs, top_k=top_k)
+            out[f"margin{margin}_k{top_k}"] = got
+    (HERE / "ance_mining.json").write_text(json.dumps(out, indent=0, sort_keys=True) + "\n")
+    print("[ance] reference ANCEMiner.mine:", {k: sum(len(x) for x in v) for k, v in out.items()}, "negatives")
+
+
 def make_pool_norm():
     g = np.random.Generator(np.random.PCG64(7))
     h = g.standard_normal((8, 64, 384), dtype=np.float32)
@@ -395,6 +459,7 @@ if __name__ == "__main__":
     make_bert(2, "stress_l2", stress=True)
     make_bert(12, "stress_l12", stress=True)
     make_kd_loss()
+    make_ance()
     make_api_schemas()
     for p in sorted(HERE.glob("*.npz")):
         print(f"{p.name}: {p.stat().st_size / 1024:.1f} KiB")

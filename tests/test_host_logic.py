@@ -233,3 +233,27 @@ def test_native_wordpiece_equals_tokenizers_library():
     from tokenizers import Tokenizer, models
 
     assert NativeWordPiece.from_hf(Tokenizer(models.WordPiece({"[UNK]": 0}, unk_token="[UNK]"))) is None
+
+
+def test_ance_miner_matches_reference_fixture():
+    """tests/golden/ance_mining.json holds what the REFERENCE'S OWN ANCEMiner.mine
+    (src/mining/miners.py:184-253) selected for a deterministic stand-in student
+    (make_golden.make_ance); the batched drop-in must select the same ids in the same order."""
+    import json
+    import sys
+
+    from conftest import GOLDEN
+
+    sys.path.insert(0, str(GOLDEN))
+    from make_golden import HashedEmbeddingStudent, ance_case
+
+    from semantic_search_kd_amd.mining import ANCEMiner
+
+    gold = json.loads((GOLDEN / "ance_mining.json").read_text())
+    queries, positives, candidates, docs = ance_case()
+    assert any(len(x) for x in gold["margin0.1_k5"]) and gold["margin0.3_k5"] != gold["margin0.0_k5"]
+    for margin in (0.1, 0.3, 0.0):
+        for top_k in (5, 2):
+            got = ANCEMiner(HashedEmbeddingStudent(), margin=margin).mine(queries, positives, candidates, docs, docs, top_k=top_k)
+            assert got == gold[f"margin{margin}_k{top_k}"], (margin, top_k)
+    assert ANCEMiner(HashedEmbeddingStudent()).mine([], [], [], {}, {}) == []

@@ -130,3 +130,45 @@ def test_packed_rejects_bad_input(enc_l2):
     with pytest.raises(ValueError, match="sum"):
         enc.encode_ragged(np.zeros(5, np.int32), np.array([3, 3], np.int32))
     assert enc.encode_ragged(np.zeros(0, np.int32), np.zeros(0, np.int32)).shape == (0, 384)
+
+
+@pytest.mark.gpu
+def test_ance_refresh_and_mine_on_gpu(gpu):
+    """ANCE refresh composition (reference: src/mining/miners.py:184-253 + docs/adr-003): re-encode the
+    corpus with the current student (packed varlen encoder, C++ tokenizer), rebuild the exact index in
+    HBM, search, apply the margin rule - checked against the same rule applied to oracle-side numpy
+    products of the very embeddings the GPU produced."""
+    from semantic_search_kd_amd import ANCEMiner, StudentModel
+    from semantic_search_kd_amd.bench_support import synthetic_passages, synthetic_vocab
+    from semantic_search_kd_amd.encoder import build_wordpiece_tokenizer
+    from semantic_search_kd_amd.mining import select_adversarial
+
+    vocab = synthetic_vocab()
+    enc = Mi355xSentenceEncoder.from_synthetic(BertConfig(num_hidden_layers=2), device="cuda:0",
+                                               tokenizer=build_wordpiece_tokenizer(vocab))
+    student = StudentModel.from_encoder(enc, "e5-small-v2-synthetic")
+    corpus = synthetic_passages(vocab, 600, seed=21)
+    ids = [f"doc{i}" for i in range(len(corpus))]
+    queries = [" ".join(c.split()[:6]) for c in corpus[:20]]      # each query is the head of a passage
+    positives = [[ids[i]] for i in range(20)]
+    miner = ANCEMiner(student, margin=0.05)
+    index = miner.refresh(ids, corpus)
+    assert index.ntotal == 600
+    got = miner.mine_from_index(queries, positives, top_k=5, search_k=50)
+    d = student.encode_documents(corpus)
+    q = student.encode_queries(queries)
+    sims = q.astype(np.float64) @ d.astype(np.float64).T
+    for qi in range(20):
+        order = [j for j in np.argsort(-sims[qi], kind="stable")[:50] if j != qi]
+        want = select_adversarial([ids[j] for j in order], sims[qi, order].astype(np.float32),
+                                  sims[qi, [qi]].astype(np.float32), 0.05, 5)
+        assert got[qi] == want
+        assert ids[qi] not in got[qi]
+    # the reference-shaped mine() over explicit candidate lists goes through the same student
+    cands = [[ids[(7 * qi + j) % 600] for j in range(30)] for qi in range(20)]
+    table = dict(zip(ids, corpus))
+    mined = miner.mine(queries, positives, cands, table, table, top_k=3)
+    for qi in range(20):
+        cj = [(7 * qi + j) % 600 for j in range(30)]
+        want = select_adversarial(cands[qi], sims[qi, cj].astype(np.float32), sims[qi, [qi]].astype(np.float32), 0.05, 3)
+        assert set(mined[qi]) == set(want)
