@@ -278,6 +278,100 @@ int sskd_encoder_forward_packed(const sskd_encoder_config* cfg, const sskd_encod
                                 void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Dimension-generic post-LN BERT-family encoder with SAVED activations and its backward pass:
+ * the student forward/backward of the KD training step (reference: src/kd/train.py:176-210,
+ * StudentModel.encode_with_gradients -> torch autograd) and the forward of the teacher
+ * cross-encoder (reference: src/mining/miners.py:128-151, src/serve/app.py:321-339).
+ * Row-major activations; hidden <= 1024; head width, hidden, intermediate multiples of 32;
+ * S a multiple of 32 (pad with mask 0).  Weights bf16 row-major [out, in]; the `_t` members are
+ * the transposes [in, out] (needed by the backward pass only, may be NULL for inference).
+ * ------------------------------------------------------------------------- */
+typedef struct sskd_generic_config {
+  int32_t vocab_size;
+  int32_t hidden;
+  int32_t layers;
+  int32_t heads;
+  int32_t intermediate;
+  int32_t max_positions;
+  int32_t type_vocab;
+  float layer_norm_eps;
+  int32_t pos_offset;     /* position id of token 0: 0 (BERT), 2 (XLM-R: padding_idx + 1) */
+} sskd_generic_config;
+
+typedef struct sskd_generic_layer_weights {
+  const void* wqkv;   /* bf16 [3H, H] (Wq; Wk; Wv) */
+  const void* wqkv_t; /* bf16 [H, 3H] */
+  const void* wo;     /* bf16 [H, H] */
+  const void* wo_t;
+  const void* w1;     /* bf16 [F, H] */
+  const void* w1_t;   /* bf16 [H, F] */
+  const void* w2;     /* bf16 [H, F] */
+  const void* w2_t;   /* bf16 [F, H] */
+  const float* bqkv;  /* [3H] */
+  const float* bo;
+  const float* ln1_g;
+  const float* ln1_b;
+  const float* b1;    /* [F] */
+  const float* b2;
+  const float* ln2_g;
+  const float* ln2_b;
+} sskd_generic_layer_weights;
+
+typedef struct sskd_generic_weights {
+  const void* word_emb;  /* bf16 [vocab, H] */
+  const void* pos_emb;   /* bf16 [max_positions, H] */
+  const void* type_emb;  /* bf16 [type_vocab, H] (row 0 is used) */
+  const float* emb_ln_g;
+  const float* emb_ln_b;
+  const sskd_generic_layer_weights* layers; /* HOST array */
+} sskd_generic_weights;
+
+/* fp32 gradient buffers with the shapes of the parameters; the backward pass ADDS into them. */
+typedef struct sskd_generic_layer_grads {
+  float* wqkv;  /* [3H, H] */
+  float* bqkv;
+  float* wo;
+  float* bo;
+  float* ln1_g;
+  float* ln1_b;
+  float* w1;
+  float* b1;
+  float* w2;
+  float* b2;
+  float* ln2_g;
+  float* ln2_b;
+} sskd_generic_layer_grads;
+
+typedef struct sskd_generic_grads {
+  float* word_emb;
+  float* pos_emb;
+  float* type_emb;  /* row 0 receives the gradient */
+  float* emb_ln_g;
+  float* emb_ln_b;
+  const sskd_generic_layer_grads* layers; /* HOST array */
+} sskd_generic_grads;
+
+/* training != 0: room for every layer's saved activations + backward scratch. */
+size_t sskd_generic_workspace_bytes(const sskd_generic_config* cfg, int B, int S, int training);
+
+/* Forward.  pool != 0: masked mean-pool (+ L2 normalise) -> d_out fp32 [B, H]; pool == 0: d_out
+ * receives the final hidden states bf16 [B, S, H].  With training != 0 the workspace afterwards
+ * holds what sskd_generic_backward needs (same B, S, same workspace). */
+int sskd_generic_forward(const sskd_generic_config* cfg, const sskd_generic_weights* w, const int32_t* d_ids,
+                         const int32_t* d_mask, int B, int S, int training, int pool, int normalize, void* d_out,
+                         void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* Backward of the pooled forward: d_dout fp32 [B, H] = d loss / d embeddings. */
+int sskd_generic_backward(const sskd_generic_config* cfg, const sskd_generic_weights* w, const sskd_generic_grads* grads,
+                          const int32_t* d_ids, const int32_t* d_mask, int B, int S, int normalize, const float* d_dout,
+                          void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* C[M, N] (bf16 or fp32, optionally +=) = A[M, K] . B[N, K]^T + bias[N]: the NT GEMM every
+ * product of the generic path goes through (test hook; K % 32 == 0). */
+int sskd_gemm_nt_bf16(const void* d_a, const void* d_b, void* d_c, const float* d_bias, int M, int N, int K,
+                      int c_is_f32, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Host WordPiece tokenizer (uncased BERT): replaces the `tokenizers` call inside
  * SentenceTransformer.encode for ASCII text (reference: AutoTokenizer use src/utils/chunk.py:26;
  * vocabulary / special ids SURVEY.md §8c).  HOST functions, multi-threaded, no device work.

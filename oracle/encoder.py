@@ -46,12 +46,22 @@ def bert_hidden_states(
 ):
     """Final (or per-layer) hidden states ``[B, S, H]`` of a post-LN BERT encoder."""
     t = {k: torch.from_numpy(np.asarray(v, np.float32)).to(dtype) for k, v in sd.items()}
+    outs = bert_hidden_states_torch(t, input_ids, attention_mask, num_layers, num_heads, eps, dtype)
+    if return_all:
+        return [o.float().numpy() for o in outs]
+    return outs[-1].float().numpy()
+
+
+def bert_hidden_states_torch(t, input_ids, attention_mask, num_layers, num_heads=12, eps=1e-12, dtype=torch.float32,
+                             pos_offset: int = 0):
+    """The same forward on a dict of torch tensors (which may require grad: torch autograd over this
+    restatement is the gradient oracle of the training path); returns the list of per-layer states."""
     ids = torch.from_numpy(np.asarray(input_ids)).long()
     mask = torch.from_numpy(np.asarray(attention_mask)).to(dtype)
     B, S = ids.shape
     x = (
         t["embeddings.word_embeddings.weight"][ids]
-        + t["embeddings.position_embeddings.weight"][:S][None]
+        + t["embeddings.position_embeddings.weight"][pos_offset : pos_offset + S][None]
         + t["embeddings.token_type_embeddings.weight"][0][None, None]
     )
     x = _ln(x, t["embeddings.LayerNorm.weight"], t["embeddings.LayerNorm.bias"], eps)
@@ -83,9 +93,17 @@ def bert_hidden_states(
         hmid = _gelu_erf(lin("intermediate.dense", x))
         x = _ln(x + lin("output.dense", hmid), t[p + "output.LayerNorm.weight"], t[p + "output.LayerNorm.bias"], eps)
         outs.append(x)
-    if return_all:
-        return [o.float().numpy() for o in outs]
-    return x.float().numpy()
+    return outs
+
+
+def embeddings_torch(t, input_ids, attention_mask, num_layers, num_heads=12, eps=1e-12, normalize=True):
+    """Differentiable masked mean-pool (+ L2 normalise) of ``bert_hidden_states_torch``."""
+    h = bert_hidden_states_torch(t, input_ids, attention_mask, num_layers, num_heads, eps)[-1]
+    m = torch.from_numpy(np.asarray(attention_mask)).to(h.dtype)[..., None]
+    e = (h * m).sum(1) / torch.clamp(m.sum(1), min=1e-9)
+    if normalize:
+        e = e / torch.clamp(e.norm(dim=1, keepdim=True), min=1e-12)
+    return e
 
 
 def mean_pool_normalize(hidden: np.ndarray, attention_mask: np.ndarray, normalize: bool = True) -> np.ndarray:

@@ -18,7 +18,7 @@ INCLUDE = REPO_ROOT / "include"
 OBJ_DIR = PKG_DIR / "build"
 LIB_PATH = PKG_DIR / "libsskd_amd.so"
 
-SOURCES = ["capi_common.hip", "search.hip", "pool.hip", "encoder.hip", "kd_loss.hip", "tokenizer.hip"]
+SOURCES = ["capi_common.hip", "search.hip", "pool.hip", "encoder.hip", "kd_loss.hip", "tokenizer.hip", "generic.hip", "train.hip"]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",
     "-O3",

@@ -59,6 +59,39 @@ class EncoderWeights(C.Structure):
     ]
 
 
+class GenericConfig(C.Structure):
+    _fields_ = [
+        ("vocab_size", C.c_int32), ("hidden", C.c_int32), ("layers", C.c_int32), ("heads", C.c_int32),
+        ("intermediate", C.c_int32), ("max_positions", C.c_int32), ("type_vocab", C.c_int32),
+        ("layer_norm_eps", C.c_float), ("pos_offset", C.c_int32),
+    ]
+
+
+GENERIC_LAYER_W = ("wqkv", "wqkv_t", "wo", "wo_t", "w1", "w1_t", "w2", "w2_t",
+                   "bqkv", "bo", "ln1_g", "ln1_b", "b1", "b2", "ln2_g", "ln2_b")
+GENERIC_LAYER_G = ("wqkv", "bqkv", "wo", "bo", "ln1_g", "ln1_b", "w1", "b1", "w2", "b2", "ln2_g", "ln2_b")
+
+
+class GenericLayerWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in GENERIC_LAYER_W]
+
+
+class GenericWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("word_emb", "pos_emb", "type_emb", "emb_ln_g", "emb_ln_b")] + [
+        ("layers", C.POINTER(GenericLayerWeights))
+    ]
+
+
+class GenericLayerGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in GENERIC_LAYER_G]
+
+
+class GenericGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("word_emb", "pos_emb", "type_emb", "emb_ln_g", "emb_ln_b")] + [
+        ("layers", C.POINTER(GenericLayerGrads))
+    ]
+
+
 class SearchTuning(C.Structure):
     """``sskd_search_tuning``: explicit launch tuning, passed to the workspace query AND the search."""
 
@@ -106,6 +139,15 @@ SIGNATURES = {
         _i,
         [C.POINTER(EncoderConfig), C.POINTER(EncoderWeights), _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _sz, _vp],
     ),
+    "sskd_generic_workspace_bytes": (_sz, [C.POINTER(GenericConfig), _i, _i, _i]),
+    "sskd_generic_forward": (
+        _i, [C.POINTER(GenericConfig), C.POINTER(GenericWeights), _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]
+    ),
+    "sskd_generic_backward": (
+        _i, [C.POINTER(GenericConfig), C.POINTER(GenericWeights), C.POINTER(GenericGrads), _vp, _vp, _i, _i, _i, _vp,
+             _vp, _sz, _vp]
+    ),
+    "sskd_gemm_nt_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sskd_tokenizer_create": (_i, [C.c_char_p, _i64, C.POINTER(C.c_void_p)]),
     "sskd_tokenizer_destroy": (None, [_vp]),
     "sskd_tokenizer_encode": (_i, [_vp, C.c_char_p, _vp, _i, _i, _i, _vp, _i64, _vp, _vp, C.POINTER(_i64)]),

@@ -1,0 +1,664 @@
+// Dimension-generic bf16 kernels (row-major activations): NT GEMM on v_mfma_f32_32x32x16_bf16,
+// transpose, LayerNorm / softmax / GELU forward + backward, embeddings, mean-pool.  See generic.h.
+#include "generic.h"
+
+namespace sskd_generic {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// ------------------------------------------------------------------------- //
+// NT GEMM: 128 x 128 block tile, 4 waves as 2 x 2, each wave 64 x 64 = 2 x 2 MFMA tiles.
+// Operand tiles go global -> registers -> LDS (rows padded by 16 B: conflict-free ds_read_b128),
+// the next tile's global loads are in flight while the current one is multiplied.
+// ------------------------------------------------------------------------- //
+template <int BK>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
+  constexpr int LDT = BK + 8;
+  constexpr int CPR = BK / 8;
+  constexpr int NCH = 128 * CPR / 256;
+  __shared__ __attribute__((aligned(16))) bf16_t As[128 * LDT];
+  __shared__ __attribute__((aligned(16))) bf16_t Bs[128 * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int z = blockIdx.z, b1 = z / p.batch2, b2 = z - b1 * p.batch2;
+  const bf16_t* A = p.A + b1 * p.sA1 + b2 * p.sA2;
+  const bf16_t* B = p.B + b1 * p.sB1 + b2 * p.sB2;
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+
+  u32x4 ra[NCH], rb[NCH];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int idx = tid + 256 * i, row = idx / CPR, c8 = idx - row * CPR;
+      const int gm = min(m0 + row, p.M - 1), gn = min(n0 + row, p.N - 1);
+      ra[i] = *reinterpret_cast<const u32x4*>(A + (int64_t)gm * p.lda + kt * BK + c8 * 8);
+      rb[i] = *reinterpret_cast<const u32x4*>(B + (int64_t)gn * p.ldb + kt * BK + c8 * 8);
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int idx = tid + 256 * i, row = idx / CPR, c8 = idx - row * CPR;
+      *reinterpret_cast<u32x4*>(As + row * LDT + c8 * 8) = ra[i];
+      *reinterpret_cast<u32x4*>(Bs + row * LDT + c8 * 8) = rb[i];
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = p.K / BK;
+  gload(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    sstore();
+    __syncthreads();
+    if (kt + 1 < nk) gload(kt + 1);
+    const bf16_t* as = As + (wm * 64 + (lane & 31)) * LDT + 8 * (lane >> 5);
+    const bf16_t* bs = Bs + (wn * 64 + (lane & 31)) * LDT + 8 * (lane >> 5);
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 a[2], b[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        a[t] = *reinterpret_cast<const bf16x8*>(as + t * 32 * LDT + ks * 16);
+        b[t] = *reinterpret_cast<const bf16x8*>(bs + t * 32 * LDT + ks * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // D[m][n]: lane holds column n = lane & 31, registers hold rows 8g + 4h + e
+  const int h = lane >> 5;
+  char* Cb = static_cast<char*>(p.C);
+  const int64_t cbase = b1 * p.sC1 + b2 * p.sC2;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+      if (n >= p.N) continue;
+      const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int m = m0 + wm * 64 + i * 32 + 8 * g + 4 * h + e;
+          if (m >= p.M) continue;
+          const float v = p.alpha * acc[i][j][4 * g + e] + bias;
+          const int64_t off = cbase + (int64_t)m * p.ldc + n;
+          if (p.c_is_f32) {
+            float* c = reinterpret_cast<float*>(Cb) + off;
+            *c = p.accumulate ? *c + v : v;
+          } else {
+            reinterpret_cast<bf16_t*>(Cb)[off] = (bf16_t)v;
+          }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void transpose_kernel(TransposeArgs p) {
+  __shared__ unsigned short tile[32][33];
+  const int z = blockIdx.z, b1 = z / p.batch2, b2 = z - b1 * p.batch2;
+  const unsigned short* in = reinterpret_cast<const unsigned short*>(p.in) + b1 * p.sI1 + b2 * p.sI2;
+  unsigned short* out = reinterpret_cast<unsigned short*>(p.out) + b1 * p.sO1 + b2 * p.sO2;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (r < p.R && c < p.C) ? in[(int64_t)r * p.ld_in + c] : (unsigned short)0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (c < p.C && r < p.R) out[(int64_t)c * p.ld_out + r] = tile[tx][ty + 8 * i];
+  }
+}
+
+// ------------------------------------------------------------------------- //
+// LayerNorm: one wave per row, H <= 1024 (two 8-wide chunks per lane)
+// ------------------------------------------------------------------------- //
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float eps, int64_t M, int H, bf16_t* __restrict__ y,
+                                                         bf16_t* __restrict__ z_save, float* __restrict__ mean_out,
+                                                         float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float v[2][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = (lane + 64 * i) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+    if (c < H) {
+      const bf16x8 av = *reinterpret_cast<const bf16x8*>(a + row * H + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = (float)av[j];
+      if (b) {
+        const bf16x8 bv = *reinterpret_cast<const bf16x8*>(b + row * H + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[i][j] += (float)bv[j];
+      }
+      if (z_save) {
+        bf16x8 zv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) zv[j] = (bf16_t)v[i][j];
+        *reinterpret_cast<bf16x8*>(z_save + row * H + c) = zv;
+        // the backward pass normalises the SAVED (bf16) z: use the same values here
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[i][j] = (float)zv[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[i][j];
+    }
+  }
+  const float mean = wave_sum(s) / H;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    if ((lane + 64 * i) * 8 < H)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) q += (v[i][j] - mean) * (v[i][j] - mean);
+  const float rstd = rsqrtf(wave_sum(q) / H + eps);
+  if (lane == 0 && mean_out) {
+    mean_out[row] = mean;
+    rstd_out[row] = rstd;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < H) {
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((v[i][j] - mean) * rstd * gamma[c + j] + beta[c + j]);
+      *reinterpret_cast<bf16x8*>(y + row * H + c) = o;
+    }
+  }
+}
+
+constexpr int LN_BWD_ROWS = 64;  // rows per workgroup (16 per wave)
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ z,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, int64_t M, int H,
+                                                     bf16_t* __restrict__ dz, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta) {
+  __shared__ float red[2][1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float dg[2][8], db[2][8], gm[2][8];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = (lane + 64 * i) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      dg[i][j] = db[i][j] = 0.f;
+      gm[i][j] = c < H ? gamma[c + j] : 0.f;
+    }
+  }
+  for (int r = 0; r < LN_BWD_ROWS / 4; ++r) {
+    const int64_t row = (int64_t)blockIdx.x * LN_BWD_ROWS + wave * (LN_BWD_ROWS / 4) + r;
+    if (row >= M) break;
+    const float mu = mean[row], rs = rstd[row];
+    float g[2][8], xh[2][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = (lane + 64 * i) * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[i][j] = xh[i][j] = 0.f;
+      if (c < H) {
+        const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dy + row * H + c);
+        const bf16x8 zv = *reinterpret_cast<const bf16x8*>(z + row * H + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d = (float)dv[j];
+          xh[i][j] = ((float)zv[j] - mu) * rs;
+          g[i][j] = d * gm[i][j];
+          dg[i][j] += d * xh[i][j];
+          db[i][j] += d;
+          s1 += g[i][j];
+          s2 += g[i][j] * xh[i][j];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / H;
+    s2 = wave_sum(s2) / H;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = (lane + 64 * i) * 8;
+      if (c < H) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(rs * (g[i][j] - s1 - xh[i][j] * s2));
+        *reinterpret_cast<bf16x8*>(dz + row * H + c) = o;
+      }
+    }
+  }
+  // the four waves' partial parameter gradients meet in LDS; one atomic per column per workgroup
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < H)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            red[0][c + j] = (w ? red[0][c + j] : 0.f) + dg[i][j];
+            red[1][c + j] = (w ? red[1][c + j] : 0.f) + db[i][j];
+          }
+      }
+    }
+    __syncthreads();
+  }
+  for (int c = threadIdx.x; c < H; c += 256) {
+    atomicAdd(dgamma + c, red[0][c]);
+    atomicAdd(dbeta + c, red[1][c]);
+  }
+}
+
+// ------------------------------------------------------------------------- //
+// softmax over rows of S <= 512 scores, one wave per row
+// ------------------------------------------------------------------------- //
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(bf16_t* __restrict__ sc, const int32_t* __restrict__ key_mask,
+                                                          int64_t rows, int heads, int S, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int64_t b = row / ((int64_t)heads * S);
+  bf16_t* p = sc + row * S;
+  float v[8];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int j = lane + 64 * i;
+    v[i] = -INFINITY;
+    if (j < S && key_mask[b * S + j] != 0) v[i] = (float)p[j] * scale;
+    mx = fmaxf(mx, v[i]);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    v[i] = mx == -INFINITY ? 0.f : __expf(v[i] - mx);
+    sum += v[i];
+  }
+  sum = wave_sum(sum);
+  const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int j = lane + 64 * i;
+    if (j < S) p[j] = (bf16_t)(v[i] * inv);
+  }
+}
+
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(bf16_t* __restrict__ dP, const bf16_t* __restrict__ P,
+                                                          int64_t rows, int S, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  bf16_t* d = dP + row * S;
+  const bf16_t* p = P + row * S;
+  float dv[8], pv[8];
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int j = lane + 64 * i;
+    dv[i] = j < S ? (float)d[j] : 0.f;
+    pv[i] = j < S ? (float)p[j] : 0.f;
+    dot += dv[i] * pv[i];
+  }
+  dot = wave_sum(dot);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int j = lane + 64 * i;
+    if (j < S) d[j] = (bf16_t)(scale * pv[i] * (dv[i] - dot));
+  }
+}
+
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16_t* __restrict__ u, bf16_t* __restrict__ h, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const bf16x8 x = reinterpret_cast<const bf16x8*>(u)[i];
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float f = (float)x[j];
+      o[j] = (bf16_t)(0.5f * f * (1.0f + erff(f * 0.70710678118654752f)));
+    }
+    reinterpret_cast<bf16x8*>(h)[i] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict__ u, const bf16_t* __restrict__ dh,
+                                                       bf16_t* __restrict__ du, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const bf16x8 x = reinterpret_cast<const bf16x8*>(u)[i];
+    const bf16x8 g = reinterpret_cast<const bf16x8*>(dh)[i];
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float f = (float)x[j];
+      const float cdf = 0.5f * (1.0f + erff(f * 0.70710678118654752f));
+      const float pdf = 0.3989422804014327f * __expf(-0.5f * f * f);
+      o[j] = (bf16_t)((float)g[j] * (cdf + f * pdf));
+    }
+    reinterpret_cast<bf16x8*>(du)[i] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void tanh_kernel(bf16_t* __restrict__ x, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    x[i] = (bf16_t)tanhf((float)x[i]);
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                  bf16_t* __restrict__ c, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const bf16x8 x = reinterpret_cast<const bf16x8*>(a)[i], y = reinterpret_cast<const bf16x8*>(b)[i];
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((float)x[j] + (float)y[j]);
+    reinterpret_cast<bf16x8*>(c)[i] = o;
+  }
+}
+
+constexpr int COLSUM_ROWS = 256;
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ dY, int64_t M, int N, int64_t ld,
+                                                     float* __restrict__ db) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= N) return;
+  const int64_t r0 = (int64_t)blockIdx.y * COLSUM_ROWS;
+  const int64_t r1 = r0 + COLSUM_ROWS < M ? r0 + COLSUM_ROWS : M;
+  float s = 0.f;
+  for (int64_t r = r0; r < r1; ++r) s += (float)dY[r * ld + c];
+  atomicAdd(db + c, s);
+}
+
+// ------------------------------------------------------------------------- //
+// embeddings
+// ------------------------------------------------------------------------- //
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int32_t* __restrict__ ids, const bf16_t* __restrict__ word,
+                                                        const bf16_t* __restrict__ pos, const bf16_t* __restrict__ type0,
+                                                        int64_t M, int S, int H, int vocab, int pos_offset,
+                                                        bf16_t* __restrict__ z) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  int id = ids[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const int t = (int)(row % S) + pos_offset;
+  for (int c = lane * 8; c < H; c += 512) {
+    const bf16x8 w = *reinterpret_cast<const bf16x8*>(word + (int64_t)id * H + c);
+    const bf16x8 p = *reinterpret_cast<const bf16x8*>(pos + (int64_t)t * H + c);
+    const bf16x8 ty = *reinterpret_cast<const bf16x8*>(type0 + c);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((float)w[j] + (float)p[j] + (float)ty[j]);
+    *reinterpret_cast<bf16x8*>(z + row * H + c) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ mask,
+                                                        const bf16_t* __restrict__ dz, int64_t M, int S, int H, int vocab,
+                                                        int pos_offset, float* __restrict__ dword,
+                                                        float* __restrict__ dpos, float* __restrict__ dtype0) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M || mask[row] == 0) return;  // padding positions carry exactly zero gradient
+  int id = ids[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const int t = (int)(row % S) + pos_offset;
+  for (int c = lane; c < H; c += 64) {
+    const float g = (float)dz[row * H + c];
+    atomicAdd(dword + (int64_t)id * H + c, g);
+    atomicAdd(dpos + (int64_t)t * H + c, g);
+    atomicAdd(dtype0 + c, g);
+  }
+}
+
+// ------------------------------------------------------------------------- //
+// masked mean pool (+ L2 normalise), one workgroup per sequence
+// ------------------------------------------------------------------------- //
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16_t* __restrict__ hidden, const int32_t* __restrict__ mask,
+                                                       int S, int H, int normalize, float* __restrict__ out,
+                                                       float* __restrict__ pooled_save) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float cnt = 0.f;
+  for (int t = 0; t < S; ++t) {
+    if (mask[(int64_t)b * S + t] == 0) continue;
+    cnt += 1.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i;
+      if (c < H) acc[i] += (float)hidden[((int64_t)b * S + t) * H + c];
+    }
+  }
+  const float n = fmaxf(cnt, 1e-9f);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    acc[i] /= n;
+    if (tid + 256 * i < H) {
+      ss += acc[i] * acc[i];
+      if (pooled_save) pooled_save[(int64_t)b * H + tid + 256 * i] = acc[i];
+    }
+  }
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) red[tid >> 6] = ss;
+  __syncthreads();
+  const float norm = fmaxf(sqrtf(red[0] + red[1] + red[2] + red[3]), 1e-12f);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i;
+    if (c < H) out[(int64_t)b * H + c] = normalize ? acc[i] / norm : acc[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ pooled,
+                                                       const int32_t* __restrict__ mask, int S, int H, int normalize,
+                                                       bf16_t* __restrict__ dhidden) {
+  __shared__ float red[2][4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float e[4], g[4];
+  float ss = 0.f, dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i;
+    e[i] = c < H ? pooled[(int64_t)b * H + c] : 0.f;
+    g[i] = c < H ? dout[(int64_t)b * H + c] : 0.f;
+    ss += e[i] * e[i];
+    dot += e[i] * g[i];
+  }
+  ss = wave_sum(ss);
+  dot = wave_sum(dot);
+  if ((tid & 63) == 0) {
+    red[0][tid >> 6] = ss;
+    red[1][tid >> 6] = dot;
+  }
+  __syncthreads();
+  float cnt = 0.f;
+  for (int t = 0; t < S; ++t) cnt += mask[(int64_t)b * S + t] != 0 ? 1.f : 0.f;
+  const float n = fmaxf(cnt, 1e-9f);
+  if (normalize) {
+    const float nrm2 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    const float nrm = fmaxf(sqrtf(nrm2), 1e-12f);
+    const float ed = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (nrm * nrm);  // (e_hat . g) / ||e||
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g[i] = (g[i] - e[i] * ed) / nrm;  // de = (g - e_hat (e_hat . g)) / ||e||
+  }
+  for (int t = 0; t < S; ++t) {
+    const float m = mask[(int64_t)b * S + t] != 0 ? 1.0f / n : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i;
+      if (c < H) dhidden[((int64_t)b * S + t) * H + c] = (bf16_t)(g[i] * m);
+    }
+  }
+}
+
+inline unsigned grid1d(int64_t n) {
+  int64_t b = sskd::ceil_div(n, 256);
+  return (unsigned)(b > 16384 ? 16384 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------- //
+// launchers
+// ------------------------------------------------------------------------- //
+int launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
+  SSKD_REQUIRE(a.M >= 0 && a.N >= 0 && a.K > 0 && a.batch1 >= 1 && a.batch2 >= 1, "gemm_nt: bad shape");
+  if (a.M == 0 || a.N == 0) return SSKD_OK;
+  SSKD_REQUIRE(a.K % 32 == 0, "gemm_nt: K=%d must be a multiple of 32", a.K);
+  SSKD_REQUIRE(a.lda % 8 == 0 && a.ldb % 8 == 0 && a.sA1 % 8 == 0 && a.sA2 % 8 == 0 && a.sB1 % 8 == 0 && a.sB2 % 8 == 0,
+               "gemm_nt: operand strides must be multiples of 8 elements");
+  SSKD_REQUIRE(a.A && a.B && a.C, "gemm_nt: null pointer");
+  SSKD_REQUIRE((reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 15) == 0,
+               "gemm_nt: operands must be 16-byte aligned");
+  SSKD_REQUIRE(!a.accumulate || a.c_is_f32, "gemm_nt: accumulate needs an fp32 output");
+  const dim3 grid((unsigned)sskd::ceil_div(a.N, 128), (unsigned)sskd::ceil_div(a.M, 128), (unsigned)(a.batch1 * a.batch2));
+  if (a.K % 64 == 0) hipLaunchKernelGGL(gemm_nt_kernel<64>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(gemm_nt_kernel<32>, grid, dim3(256), 0, st, a);
+  return sskd::check_launch("gemm_nt_kernel");
+}
+
+int launch_transpose(const TransposeArgs& a, hipStream_t st) {
+  if (a.R == 0 || a.C == 0) return SSKD_OK;
+  const dim3 grid((unsigned)sskd::ceil_div(a.C, 32), (unsigned)sskd::ceil_div(a.R, 32), (unsigned)(a.batch1 * a.batch2));
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, st, a);
+  return sskd::check_launch("transpose_kernel");
+}
+
+int launch_add_ln_fwd(const bf16_t* a, const bf16_t* b, const float* gamma, const float* beta, float eps,
+                      int64_t M, int H, bf16_t* y, bf16_t* z_save, float* mean, float* rstd, hipStream_t st) {
+  SSKD_REQUIRE(H % 8 == 0 && H <= 1024, "layernorm: hidden=%d must be a multiple of 8, at most 1024", H);
+  if (M == 0) return SSKD_OK;
+  hipLaunchKernelGGL(add_ln_fwd_kernel, dim3((unsigned)sskd::ceil_div(M, 4)), dim3(256), 0, st, a, b, gamma, beta, eps,
+                     M, H, y, z_save, mean, rstd);
+  return sskd::check_launch("add_ln_fwd_kernel");
+}
+
+int launch_ln_bwd(const bf16_t* dy, const bf16_t* z, const float* mean, const float* rstd, const float* gamma,
+                  int64_t M, int H, bf16_t* dz, float* dgamma, float* dbeta, hipStream_t st) {
+  SSKD_REQUIRE(H % 8 == 0 && H <= 1024, "layernorm: hidden=%d must be a multiple of 8, at most 1024", H);
+  if (M == 0) return SSKD_OK;
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)sskd::ceil_div(M, LN_BWD_ROWS)), dim3(256), 0, st, dy, z, mean, rstd,
+                     gamma, M, H, dz, dgamma, dbeta);
+  return sskd::check_launch("ln_bwd_kernel");
+}
+
+int launch_softmax_fwd(bf16_t* scores, const int32_t* key_mask, int B, int heads, int S, float scale, hipStream_t st) {
+  SSKD_REQUIRE(S >= 1 && S <= 512, "softmax: S=%d outside [1, 512]", S);
+  const int64_t rows = (int64_t)B * heads * S;
+  if (rows == 0) return SSKD_OK;
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)sskd::ceil_div(rows, 4)), dim3(256), 0, st, scores, key_mask,
+                     rows, heads, S, scale);
+  return sskd::check_launch("softmax_fwd_kernel");
+}
+
+int launch_softmax_bwd(bf16_t* dP, const bf16_t* P, int64_t rows, int S, float scale, hipStream_t st) {
+  SSKD_REQUIRE(S >= 1 && S <= 512, "softmax: S=%d outside [1, 512]", S);
+  if (rows == 0) return SSKD_OK;
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)sskd::ceil_div(rows, 4)), dim3(256), 0, st, dP, P, rows, S, scale);
+  return sskd::check_launch("softmax_bwd_kernel");
+}
+
+int launch_gelu_fwd(const bf16_t* u, bf16_t* h, int64_t n, hipStream_t st) {
+  SSKD_REQUIRE(n % 8 == 0, "gelu: element count must be a multiple of 8");
+  if (n == 0) return SSKD_OK;
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid1d(n / 8)), dim3(256), 0, st, u, h, n / 8);
+  return sskd::check_launch("gelu_fwd_kernel");
+}
+
+int launch_gelu_bwd(const bf16_t* u, const bf16_t* dh, bf16_t* du, int64_t n, hipStream_t st) {
+  SSKD_REQUIRE(n % 8 == 0, "gelu: element count must be a multiple of 8");
+  if (n == 0) return SSKD_OK;
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid1d(n / 8)), dim3(256), 0, st, u, dh, du, n / 8);
+  return sskd::check_launch("gelu_bwd_kernel");
+}
+
+int launch_tanh_fwd(bf16_t* x, int64_t n, hipStream_t st) {
+  if (n == 0) return SSKD_OK;
+  hipLaunchKernelGGL(tanh_kernel, dim3(grid1d(n)), dim3(256), 0, st, x, n);
+  return sskd::check_launch("tanh_kernel");
+}
+
+int launch_colsum(const bf16_t* dY, int64_t M, int N, int64_t ld, float* db, hipStream_t st) {
+  if (M == 0 || N == 0) return SSKD_OK;
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)sskd::ceil_div(N, 256), (unsigned)sskd::ceil_div(M, COLSUM_ROWS)),
+                     dim3(256), 0, st, dY, M, N, ld, db);
+  return sskd::check_launch("colsum_kernel");
+}
+
+int launch_add(const bf16_t* a, const bf16_t* b, bf16_t* c, int64_t n, hipStream_t st) {
+  SSKD_REQUIRE(n % 8 == 0, "add: element count must be a multiple of 8");
+  if (n == 0) return SSKD_OK;
+  hipLaunchKernelGGL(add_kernel, dim3(grid1d(n / 8)), dim3(256), 0, st, a, b, c, n / 8);
+  return sskd::check_launch("add_kernel");
+}
+
+int launch_embed_fwd(const int32_t* ids, const int32_t* mask, const bf16_t* word, const bf16_t* pos, const bf16_t* type0,
+                     int B, int S, int H, int vocab, int pos_offset, bf16_t* z, hipStream_t st) {
+  (void)mask;
+  SSKD_REQUIRE(H % 8 == 0, "embed: hidden must be a multiple of 8");
+  const int64_t M = (int64_t)B * S;
+  if (M == 0) return SSKD_OK;
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3((unsigned)sskd::ceil_div(M, 4)), dim3(256), 0, st, ids, word, pos, type0, M,
+                     S, H, vocab, pos_offset, z);
+  return sskd::check_launch("embed_fwd_kernel");
+}
+
+int launch_embed_bwd(const int32_t* ids, const int32_t* mask, const bf16_t* dz, int B, int S, int H, int vocab,
+                     int pos_offset, float* dword, float* dpos, float* dtype0, hipStream_t st) {
+  const int64_t M = (int64_t)B * S;
+  if (M == 0) return SSKD_OK;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)sskd::ceil_div(M, 4)), dim3(256), 0, st, ids, mask, dz, M, S, H,
+                     vocab, pos_offset, dword, dpos, dtype0);
+  return sskd::check_launch("embed_bwd_kernel");
+}
+
+int launch_pool_fwd(const bf16_t* hidden, const int32_t* mask, int B, int S, int H, int normalize, float* out,
+                    float* pooled_save, hipStream_t st) {
+  SSKD_REQUIRE(H <= 1024, "pool: hidden=%d > 1024", H);
+  if (B == 0) return SSKD_OK;
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3(B), dim3(256), 0, st, hidden, mask, S, H, normalize, out, pooled_save);
+  return sskd::check_launch("pool_fwd_kernel");
+}
+
+int launch_pool_bwd(const float* dout, const float* pooled, const int32_t* mask, int B, int S, int H, int normalize,
+                    bf16_t* dhidden, hipStream_t st) {
+  SSKD_REQUIRE(H <= 1024, "pool: hidden=%d > 1024", H);
+  if (B == 0) return SSKD_OK;
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3(B), dim3(256), 0, st, dout, pooled, mask, S, H, normalize, dhidden);
+  return sskd::check_launch("pool_bwd_kernel");
+}
+
+}  // namespace sskd_generic

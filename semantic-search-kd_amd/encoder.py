@@ -148,6 +148,9 @@ class Mi355xSentenceEncoder:
             state_dict = load_state_dict(model_dir)
         self.config = config or BertConfig()
         self.weights = DeviceWeights(self.config, state_dict, self.device)
+        self._host_state = state_dict      # fp32 masters, the seed of the trainable copy
+        self._trainable = None             # training.TrainableEncoder, created on first use
+        self._trainable_versions = None
         self._tokenizer = None
         self._native_tok: Optional[NativeWordPiece] = None
         self.tokenizer = tokenizer if tokenizer is not None else _load_tokenizer(model_dir)
@@ -186,6 +189,48 @@ class Mi355xSentenceEncoder:
         sd = synthetic_state_dict(cfg, stress=stress)
         return cls(None, device, config=cfg, state_dict=sd, tokenizer=tokenizer, **kw)
 
+    # ------------------------------------------------------ training surface (src/kd/train.py:126-127,154)
+    def trainable(self):
+        """The fp32 master parameters as an ``nn.Module`` whose forward/backward run in HIP
+        (``training.TrainableEncoder``); created on first use from the loaded weights."""
+        if self._trainable is None:
+            from .training import TrainableEncoder
+
+            self._trainable = TrainableEncoder(self.config, self._host_state, self.device)
+            self._trainable_versions = tuple(p._version for p in self._trainable.parameters())
+        return self._trainable
+
+    def parameters(self):
+        return self.trainable().parameters()
+
+    def named_parameters(self):
+        return self.trainable().named_parameters()
+
+    def train(self, mode: bool = True):
+        self.trainable().train(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def to(self, device):
+        if _resolve_device(str(device)) != self.device:
+            raise RuntimeError(f"the encoder lives on {self.device}; re-create it on {device}")
+        return self
+
+    def sync_inference_weights(self) -> bool:
+        """Re-tile the bf16 inference weights from the trained fp32 masters when they changed
+        (called by ``encode`` so that evaluation after optimizer steps sees the new weights)."""
+        if self._trainable is None:
+            return False
+        versions = tuple(p._version for p in self._trainable.parameters())
+        if versions == self._trainable_versions:
+            return False
+        self._host_state = self._trainable.state_dict_numpy()
+        self.weights = DeviceWeights(self.config, self._host_state, self.device)
+        self._trainable_versions = versions
+        return True
+
     # ------------------------------------------------------ SentenceTransformer API
     def get_sentence_embedding_dimension(self) -> int:
         return self.config.hidden_size
@@ -218,6 +263,7 @@ class Mi355xSentenceEncoder:
         Everything is enqueued on the current stream; no host synchronisation.
         """
         lib = _native.load()
+        self.sync_inference_weights()
         ids = _as_device_i32(input_ids, self.device)
         if ids.dim() != 2:
             raise ValueError(f"input_ids must be [B, S], got {tuple(ids.shape)}")
@@ -272,6 +318,7 @@ class Mi355xSentenceEncoder:
         no length sorting, no per-batch padding, no scatter.  Launches are cut by a token budget
         (LAUNCH_TOKENS), not by a caller batch size.  Enqueued on the current stream."""
         lib = _native.load()
+        self.sync_inference_weights()
         lengths = np.ascontiguousarray(lengths, np.int32)
         flat_ids = np.ascontiguousarray(flat_ids, np.int32)
         n = int(lengths.shape[0])

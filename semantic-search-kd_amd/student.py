@@ -103,12 +103,14 @@ class StudentModel:
         return self.encode(list(documents), batch_size=batch_size, show_progress=show_progress, **kwargs)
 
     def encode_with_gradients(self, texts: List[str], normalize: bool = True):
-        """Training entry point of the reference (src/kd/train.py:180-187). The MI355X backend is
-        forward-only this round (KD training is a "next" row of the scope table)."""
-        raise NotImplementedError(
-            "encode_with_gradients: the MI355X encoder is inference-only; the KD training step is not "
-            "part of the embedding-and-search hot path"
-        )
+        """Training entry point of the reference (src/kd/train.py:180-187): embeddings ``[n, 384]`` on
+        ``self.device`` that carry gradients back to ``self.model.parameters()``.  Forward (saving
+        activations) and backward are HIP kernels behind one autograd function (training.py); E5
+        prefixes are the caller's business here exactly as in the reference's training loop."""
+        if isinstance(texts, str):
+            texts = [texts]
+        tok = self.model.tokenize(list(texts))
+        return self.model.trainable()(tok["input_ids"], tok["attention_mask"], normalize=normalize)
 
     # -------------------------------------------------------------- similarity
     def compute_similarity(self, query_embeddings: np.ndarray, doc_embeddings: np.ndarray) -> np.ndarray:

@@ -359,6 +359,51 @@ def make_bert(layers: int, tag: str, stress: bool = False):
     )
 
 
+GRAD_CFG = dict(vocab_size=600, hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512,
+                max_position_embeddings=64)
+
+
+def grad_case():
+    cfg = BertConfig(**GRAD_CFG)
+    sd = synthetic_state_dict(cfg)
+    ids, mask = enc_oracle.synthetic_token_ids(5, 40, seed=31, vocab=cfg.vocab_size, lengths=[40, 33, 17, 8, 2])
+    g = np.random.Generator(np.random.PCG64(32))
+    probe = g.standard_normal((5, cfg.hidden_size)).astype(np.float32)  # loss = sum(embeddings * probe)
+    return cfg, sd, ids, mask, probe
+
+
+def make_bert_grads():
+    """Parameter gradients of ``transformers.BertModel`` + mean-pool + L2-normalise by torch autograd
+    (the reference's training path: src/kd/train.py:176-210 backpropagates through exactly these
+    modules) on a small synthetic model; the oracle restatement's autograd is asserted equal here.
+    Stored in float16 (the test gate is a cosine per parameter tensor)."""
+    cfg, sd, ids, mask, probe = grad_case()
+    model = hf_bert(cfg, sd).train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    out = model(input_ids=torch.from_numpy(ids).long(), attention_mask=torch.from_numpy(mask).long())
+    h = out.last_hidden_state
+    m = torch.from_numpy(mask).float()[..., None]
+    e = (h * m).sum(1) / torch.clamp(m.sum(1), min=1e-9)
+    e = torch.nn.functional.normalize(e, p=2, dim=1)
+    (e * torch.from_numpy(probe)).sum().backward()
+    hf_grads = {k: p.grad.numpy().copy() for k, p in model.named_parameters() if p.grad is not None}
+    t = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in sd.items()}
+    eo = enc_oracle.embeddings_torch(t, ids, mask, cfg.num_hidden_layers, cfg.num_attention_heads)
+    assert np.abs(eo.detach().numpy() - e.detach().numpy()).max() < 1e-5
+    (eo * torch.from_numpy(probe)).sum().backward()
+    store = {"embeddings": e.detach().numpy()}
+    for k, g in hf_grads.items():
+        og = t[k].grad.numpy()
+        denom = np.abs(g).max() + 1e-12
+        assert np.abs(og - g).max() <= 2e-4 * denom + 1e-7, (k, np.abs(og - g).max(), denom)
+        store["grad:" + k] = (g / denom).astype(np.float16)   # scaled to max |g| = 1 (fp16 range)
+        store["amax:" + k] = np.float64(denom)
+    np.savez_compressed(HERE / "bert_grads_small.npz", **store)
+    print(f"[bert_grads_small] {len(hf_grads)} parameter tensors, oracle autograd == transformers autograd")
+
+
 def make_kd_loss():
     """Losses and autograd gradients from the REFERENCE'S OWN code (src/kd/losses.py), imported from
     /root/reference in this container only.  Its one missing dependency is a logging package used
@@ -458,6 +503,7 @@ if __name__ == "__main__":
     make_bert(12, "l12")
     make_bert(2, "stress_l2", stress=True)
     make_bert(12, "stress_l12", stress=True)
+    make_bert_grads()
     make_kd_loss()
     make_ance()
     make_api_schemas()

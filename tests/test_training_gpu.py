@@ -1,0 +1,168 @@
+"""Student forward / backward (BASELINE cfg 4) on the GPU vs torch autograd over the fp32 oracle.
+
+Gradient oracle: ``oracle.encoder.embeddings_torch`` under torch autograd on the CPU; that restatement's
+gradients are pinned to ``transformers.BertModel`` autograd by tests/golden/bert_grads_small.npz
+(make_golden.make_bert_grads; the CPU test below).  Tolerance (bf16 compute, fp32 accumulation):
+cosine >= 0.999 per parameter tensor, norms within 3 %.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import encoder as enc_oracle
+from oracle import kd_losses as kd_oracle
+from semantic_search_kd_amd import BertConfig, synthetic_state_dict
+
+
+def _cos(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
+
+
+def _oracle_grads(sd, cfg, ids, mask, probe):
+    t = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in sd.items()}
+    e = enc_oracle.embeddings_torch(t, ids, mask, cfg.num_hidden_layers, cfg.num_attention_heads)
+    (e * torch.from_numpy(probe)).sum().backward()
+    return e.detach().numpy(), {k: v.grad.numpy() for k, v in t.items()}
+
+
+def test_oracle_autograd_is_pinned_by_transformers_fixture():
+    """CPU: torch autograd over oracle/encoder.py reproduces the committed transformers.BertModel gradients."""
+    import sys
+
+    sys.path.insert(0, str(GOLDEN))
+    from make_golden import grad_case
+
+    gold = np.load(GOLDEN / "bert_grads_small.npz")
+    cfg, sd, ids, mask, probe = grad_case()
+    emb, grads = _oracle_grads(sd, cfg, ids, mask, probe)
+    np.testing.assert_allclose(emb, gold["embeddings"], atol=1e-5)
+    names = [k[5:] for k in gold.files if k.startswith("grad:")]
+    assert len(names) == 37
+    top = max(float(gold["amax:" + k]) for k in names)
+    for k in names:
+        want = gold["grad:" + k].astype(np.float64) * float(gold["amax:" + k])
+        if float(gold["amax:" + k]) < 1e-6 * top:
+            # mathematically zero (a key bias shifts every score of a query alike: softmax ignores it)
+            assert np.abs(grads[k]).max() < 1e-6 * top and "key.bias" in k
+            continue
+        assert _cos(grads[k], want) > 0.99999, k
+        assert abs(np.linalg.norm(grads[k]) / np.linalg.norm(want) - 1.0) < 2e-3, k
+
+
+@pytest.mark.gpu
+def test_nt_gemm_matches_torch(gpu, native_lib):
+    from semantic_search_kd_amd import _native
+
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for M, N, K, f32, acc in ((128, 128, 64, 0, 0), (300, 130, 96, 1, 0), (1000, 384, 384, 0, 0), (77, 1536, 32, 1, 1),
+                               (384, 1152, 4096, 1, 1), (5, 3, 32, 0, 0)):
+        a = torch.randn((M, K), generator=g, device="cuda").to(torch.bfloat16)
+        b = torch.randn((N, K), generator=g, device="cuda").to(torch.bfloat16)
+        bias = torch.randn(N, generator=g, device="cuda")
+        c0 = torch.randn((M, N), generator=g, device="cuda") if acc else None
+        c = (c0.clone() if acc else torch.empty((M, N), device="cuda", dtype=torch.float32 if f32 else torch.bfloat16))
+        _native.check(native_lib.sskd_gemm_nt_bf16(a.data_ptr(), b.data_ptr(), c.data_ptr(), bias.data_ptr(), M, N, K, f32, acc,
+                                                   int(torch.cuda.current_stream().cuda_stream)))
+        want = a.float() @ b.float().T + bias + (c0 if acc else 0)
+        tol = 2e-2 * want.abs().max().item() if not f32 else 1e-3 * max(want.abs().max().item(), 1.0)
+        assert (c.float() - want).abs().max().item() <= tol, (M, N, K)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims", ["small", "e5"])
+def test_encoder_gradients_match_oracle_autograd(gpu, dims):
+    from semantic_search_kd_amd.training import TrainableEncoder
+
+    if dims == "small":
+        cfg = BertConfig(vocab_size=600, hidden_size=128, num_hidden_layers=2, num_attention_heads=4,
+                         intermediate_size=512, max_position_embeddings=64)
+        ids, mask = enc_oracle.synthetic_token_ids(5, 40, seed=31, vocab=600, lengths=[40, 33, 17, 8, 2])
+    else:  # the e5-small-v2 architecture, 2 layers, reduced vocabulary (the embedding table is a gather)
+        cfg = BertConfig(vocab_size=2000, num_hidden_layers=2)
+        ids, mask = enc_oracle.synthetic_token_ids(6, 70, seed=33, vocab=2000, lengths=[70, 64, 33, 32, 9, 2])
+    sd = synthetic_state_dict(cfg)
+    probe = np.random.Generator(np.random.PCG64(5)).standard_normal((ids.shape[0], cfg.hidden_size)).astype(np.float32)
+    want_e, want_g = _oracle_grads(sd, cfg, ids, mask, probe)
+    model = TrainableEncoder(cfg, sd, "cuda:0")
+    emb = model(ids, mask, normalize=True)
+    assert emb.requires_grad and emb.shape == want_e.shape
+    e = emb.detach().cpu().numpy()
+    assert min(_cos(e[i], want_e[i]) for i in range(e.shape[0])) >= 0.999
+    (emb * torch.from_numpy(probe).cuda()).sum().backward()
+    top = max(np.abs(v).max() for v in want_g.values())
+    for name in model.names:
+        got = model.p(name).grad.cpu().numpy()
+        ref = want_g[name]
+        if np.abs(ref).max() < 1e-6 * top:  # mathematically zero (key biases): only rounding noise may show
+            assert np.abs(got).max() < 2e-2 * top, name
+            continue
+        assert _cos(got, ref) >= 0.999, (name, _cos(got, ref))
+        assert abs(np.linalg.norm(got) / np.linalg.norm(ref) - 1.0) < 0.03, name
+    # rows of the embedding tables that no token touched receive exactly zero gradient
+    gw = model.p("embeddings.word_embeddings.weight").grad
+    untouched = torch.ones(cfg.vocab_size, dtype=torch.bool)
+    untouched[torch.from_numpy(ids[mask.astype(bool)]).long()] = False
+    assert not gw[untouched.cuda()].any()
+
+
+@pytest.mark.gpu
+def test_kd_training_step_matches_oracle_and_learns(gpu):
+    """The reference's step (src/kd/train.py:176-210) on the HIP path: encode_with_gradients twice ->
+    q @ d.T -> CombinedKDLoss (HIP) -> backward -> AdamW; loss and gradients vs the oracle chain
+    (oracle encoder autograd + the reference-pinned KD-loss oracle), then a few steps lower the loss."""
+    from semantic_search_kd_amd import CombinedKDLoss, StudentModel
+    from semantic_search_kd_amd.encoder import Mi355xSentenceEncoder
+
+    cfg = BertConfig(vocab_size=2000, num_hidden_layers=2)
+    sd = synthetic_state_dict(cfg)
+    enc = Mi355xSentenceEncoder(None, "cuda:0", config=cfg, state_dict=sd)
+    student = StudentModel.from_encoder(enc, "e5-small-v2-synthetic")
+    q_ids, q_mask = enc_oracle.synthetic_token_ids(1, 12, seed=41, vocab=2000)
+    d_ids, d_mask = enc_oracle.synthetic_token_ids(9, 60, seed=42, vocab=2000, lengths=[60, 55, 41, 33, 32, 20, 11, 7, 3])
+    teacher = np.random.Generator(np.random.PCG64(43)).standard_normal(9).astype(np.float32) * 3.0
+    model = enc.trainable()
+    student.model.train()
+    loss_fn = CombinedKDLoss()
+
+    def step_loss():
+        q = model(q_ids, q_mask)
+        d = model(d_ids, d_mask)
+        scores = torch.matmul(q, d.T)[0]
+        return loss_fn(scores.unsqueeze(0), torch.from_numpy(teacher).cuda().unsqueeze(0)), scores
+
+    out, scores = step_loss()
+    out["loss"].backward()
+    # oracle chain
+    t = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in sd.items()}
+    qo = enc_oracle.embeddings_torch(t, q_ids, q_mask, 2)
+    do = enc_oracle.embeddings_torch(t, d_ids, d_mask, 2)
+    so = torch.matmul(qo, do.T)[0]
+    ref, ref_ds = kd_oracle.combined(so.detach().numpy()[None], teacher[None], loss_fn.current_temperature)
+    so.backward(gradient=torch.from_numpy(ref_ds[0].astype(np.float32)))
+    assert np.abs(scores.detach().cpu().numpy() - so.detach().numpy()).max() < 5e-3
+    assert abs(float(out["loss"]) - ref["loss"]) < 2e-2 * max(1.0, abs(ref["loss"]))
+    checked = 0
+    for name in model.names:
+        refg = t[name].grad.numpy()
+        if "key.bias" in name or np.linalg.norm(refg) < 1e-10:
+            continue
+        c = _cos(model.p(name).grad.cpu().numpy(), refg)
+        assert c >= 0.995, (name, c)
+        checked += 1
+    assert checked >= 30
+    # optimisation: the same batch, a few AdamW steps
+    opt = torch.optim.AdamW(student.model.parameters(), lr=2e-4)
+    first = None
+    for _ in range(8):
+        opt.zero_grad()
+        out, _ = step_loss()
+        out["loss"].backward()
+        opt.step()
+        first = float(out["loss"]) if first is None else first
+    assert float(out["loss"]) < first
+    # inference weights follow the trained masters on the next encode
+    before = enc.encode_token_ids(d_ids, d_mask).cpu().numpy()
+    want = model(d_ids, d_mask).detach().cpu().numpy()
+    assert min(_cos(before[i], want[i]) for i in range(9)) > 0.999
