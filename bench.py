@@ -187,6 +187,8 @@ def main() -> None:
     ap.add_argument("--no-encode", action="store_true")
     ap.add_argument("--no-ragged", action="store_true", help="skip the ragged-length encode leg")
     ap.add_argument("--no-text", action="store_true", help="skip the text -> embedding leg")
+    ap.add_argument("--no-train", action="store_true", help="skip the KD training-step leg (BASELINE cfg 4)")
+    ap.add_argument("--no-teacher", action="store_true", help="skip the teacher cross-encoder leg (BASELINE cfg 5 model)")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous + one all-gather over gloo on CPU, no GPU work: tests the N > 1 launch plumbing")
     args = ap.parse_args()
@@ -381,6 +383,14 @@ def main() -> None:
                                           text=not args.no_text and rank == 0)
             if rank == 0 and world == 1 and not args.no_cpu_baseline:
                 line["encode"]["cpu_baseline"] = cpu_encode_baseline()
+        if not args.no_teacher:
+            from semantic_search_kd_amd.bench_support import bench_teacher
+
+            line["teacher"] = bench_teacher(dev, world, max(2, args.steps // 2), 1, barrier)
+        if rank == 0 and world == 1 and not args.no_train:
+            from semantic_search_kd_amd.bench_support import bench_kd_step
+
+            line["kd_step"] = bench_kd_step(dev)
 
     # ---- CPU baseline: rank 0, N = 1 only --------------------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -366,6 +366,17 @@ int sskd_generic_backward(const sskd_generic_config* cfg, const sskd_generic_wei
                           const int32_t* d_ids, const int32_t* d_mask, int B, int S, int normalize, const float* d_dout,
                           void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* Teacher cross-encoder score (replaces CrossEncoder.predict behind TeacherModel.score; reference:
+ * src/mining/miners.py:135-137, src/serve/app.py:325-326; model = XLM-R-large shaped
+ * XLMRobertaForSequenceClassification with one label, docs/adr-002): generic encoder forward ->
+ * hidden state of token 0 -> dense [H, H] + tanh -> out_proj [1, H] -> d_logits fp32 [B] (raw logits).
+ * head weights bf16 row-major [out, in], biases fp32. */
+size_t sskd_teacher_workspace_bytes(const sskd_generic_config* cfg, int B, int S);
+int sskd_teacher_score(const sskd_generic_config* cfg, const sskd_generic_weights* w, const void* d_head_dense_w,
+                       const float* d_head_dense_b, const void* d_head_out_w, const float* d_head_out_b,
+                       const int32_t* d_ids, const int32_t* d_mask, int B, int S, float* d_logits, void* d_workspace,
+                       size_t workspace_bytes, void* stream);
+
 /* C[M, N] (bf16 or fp32, optionally +=) = A[M, K] . B[N, K]^T + bias[N]: the NT GEMM every
  * product of the generic path goes through (test hook; K % 32 == 0). */
 int sskd_gemm_nt_bf16(const void* d_a, const void* d_b, void* d_c, const float* d_bias, int M, int N, int K,

@@ -14,12 +14,15 @@ from .encoder import Mi355xSentenceEncoder, build_wordpiece_tokenizer  # noqa: F
 from .student import StudentModel  # noqa: F401
 from .losses import CombinedKDLoss, ContrastiveLoss, ListwiseKDLoss, MarginMSELoss  # noqa: F401
 from .mining import ANCEMiner  # noqa: F401
+from .teacher import TeacherConfig, TeacherModel  # noqa: F401
 from .bench_support import bench_encode, encoder_smoke_embeddings  # noqa: F401
 
 Mi355xIndexBuilder = FAISSIndexBuilder
 
 __all__ = [
     "ANCEMiner",
+    "TeacherConfig",
+    "TeacherModel",
     "CombinedKDLoss",
     "ContrastiveLoss",
     "ListwiseKDLoss",

@@ -184,6 +184,104 @@ def bench_encode_text(enc: Mi355xSentenceEncoder, device, n_docs: int = 32768, p
     }
 
 
+def bench_kd_step(device, tuples: int = 32, docs_per_query: int = 8, q_len: int = 32, d_len: int = 256,
+                  steps: int = 5, warmup: int = 2):
+    """BASELINE cfg 4: one KD training step = student forward over ``tuples`` queries and their
+    (positive + 7 hard negatives) passages with saved activations, scores ``q . d``, the fused
+    Margin-MSE + listwise-KL + InfoNCE loss, backward through the encoder, AdamW update (reference
+    step: src/kd/train.py:176-210, batched over the tuples instead of one query at a time).
+    e5-small-v2 architecture, random-init weights, synthetic ids, bf16 compute / fp32 gradients.
+    FLOPs: forward FLOPs of SURVEY.md section 8(d) on the step's tokens x 3 (backward = 2 x forward)."""
+    from .losses import CombinedKDLoss
+    from .training import TrainableEncoder
+    from .weights import synthetic_state_dict
+
+    cfg = BertConfig()
+    model = TrainableEncoder(cfg, synthetic_state_dict(cfg), device)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-5)
+    loss_fn = CombinedKDLoss()
+    q_ids, q_mask = synthetic_ids(tuples, q_len, cfg.vocab_size, device, seed=1)
+    d_ids, d_mask = synthetic_ids(tuples * docs_per_query, d_len, cfg.vocab_size, device, seed=2)
+    g = torch.Generator(device=device).manual_seed(3)
+    teacher = torch.randn((tuples, docs_per_query), generator=g, device=device) * 3.0
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        q = model(q_ids, q_mask)
+        d = model(d_ids, d_mask).view(tuples, docs_per_query, -1)
+        scores = torch.einsum("th,tdh->td", q, d)
+        out = loss_fn(scores, teacher)
+        out["loss"].backward()
+        opt.step()
+        return out["loss"]
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    flops = 3.0 * (encoder_flops(tuples * q_len, q_len, cfg) + encoder_flops(tuples * docs_per_query * d_len, d_len, cfg))
+    return {
+        "value": round(tuples / dt, 1),
+        "unit": "tuples/s",
+        "ms_per_step": round(dt * 1e3, 3),
+        "dtype": "bf16",
+        "workload": f"{tuples} (query, positive, {docs_per_query - 1} hard-negative) tuples per step: queries {q_len} tokens, "
+                    f"passages {d_len} tokens; forward + fused KD loss + backward + AdamW",
+        "tokens_per_s": round((tuples * q_len + tuples * docs_per_query * d_len) / dt, 1),
+        "final_loss": float(loss.detach()),
+        "roofline": {"bound": "mfma", "achieved": round(flops / dt / 1e12, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": round(flops / dt / 1e12 / MFMA_BF16_PEAK_TF, 4), "algorithmic_flops_per_step": flops},
+    }
+
+
+def bench_teacher(device, world: int, steps: int, warmup: int, barrier, pairs: int = 128, seq_len: int = 256):
+    """BASELINE cfg 5 model: XLM-R-large-shaped cross-encoder (24 layers, hidden 1024, 16 heads, FFN 4096;
+    bge-reranker-large) scoring (query, passage) pairs of ``seq_len`` tokens, ``pairs`` per rank per step;
+    pure data parallel (every rank scores its own pairs, no communication).  Random-init weights drawn on
+    the device, synthetic ids.  FLOPs per token: 24 (2 (4 H^2 + 2 H F) + 4 S H)."""
+    import torch.distributed as dist
+
+    from .teacher import TeacherConfig, TeacherModel
+
+    cfg = TeacherConfig()
+    teacher = TeacherModel.from_random_device(cfg, str(device), seed=int(device.index or 0))
+    g = torch.Generator(device=device).manual_seed(5)
+    ids = torch.randint(4, cfg.vocab_size, (pairs, seq_len), generator=g, device=device, dtype=torch.int32)
+    ids[:, 0] = 0
+    ids[:, -1] = 2
+    mask = torch.ones_like(ids)
+    out = torch.empty(pairs, dtype=torch.float32, device=device)
+    for _ in range(max(warmup, 1)):
+        teacher.score_token_ids(ids, mask, out=out)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        teacher.score_token_ids(ids, mask, out=out)
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    h, f = cfg.hidden_size, cfg.intermediate_size
+    flops = pairs * seq_len * cfg.num_hidden_layers * (2.0 * (4 * h * h + 2 * h * f) + 4.0 * seq_len * h)
+    tf = flops * steps / dt / 1e12
+    return {
+        "value": round(world * pairs * steps / dt, 1),
+        "unit": "pairs/s",
+        "ms_per_step": round(dt / steps * 1e3, 3),
+        "dtype": "bf16",
+        "workload": f"XLM-R-large-shaped cross-encoder, {pairs} pairs x {seq_len} tokens per GPU per step, random-init weights",
+        "finite": bool(torch.isfinite(out).all()),
+        "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": round(tf / MFMA_BF16_PEAK_TF, 4), "algorithmic_flops_per_step": flops},
+    }
+
+
 def encoder_smoke_embeddings(device: str = "cuda:0"):
     """Tiny forward of a 2-layer synthetic encoder on the golden l2 input; returns (embeddings, ids, mask)
     for the caller (``__graft_entry__.smoke``) to compare against the committed golden vectors."""

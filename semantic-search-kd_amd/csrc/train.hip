@@ -408,6 +408,13 @@ int layer_backward(const Dims& d, const sskd_generic_layer_weights& lw, const ss
   return SSKD_OK;
 }
 
+// Cross-encoder head input: hidden state of token 0 (<s>) of every sequence
+__global__ __launch_bounds__(256) void gather_first_token_kernel(const bf16_t* __restrict__ hidden, int S, int H,
+                                                                 bf16_t* __restrict__ out) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < H; c += 256) out[(int64_t)b * H + c] = hidden[(int64_t)b * S * H + c];
+}
+
 }  // namespace
 
 extern "C" {
@@ -482,6 +489,43 @@ int sskd_generic_backward(const sskd_generic_config* cfg, const sskd_generic_wei
   TRY(launch_ln_bwd(dx, sv.z0, sv.mean0, sv.rstd0, w->emb_ln_g, d.M, d.H, sv.tH0, grads->emb_ln_g, grads->emb_ln_b, st));
   return launch_embed_bwd(d_ids, d_mask, sv.tH0, B, S, d.H, cfg->vocab_size, cfg->pos_offset, grads->word_emb,
                           grads->pos_emb, grads->type_emb, st);
+}
+
+size_t sskd_teacher_workspace_bytes(const sskd_generic_config* cfg, int B, int S) {
+  const size_t enc = sskd_generic_workspace_bytes(cfg, B, S, 0);
+  if (enc == 0) return 0;
+  const size_t BH = ((size_t)(B > 32 ? B : 32) * cfg->hidden * sizeof(bf16_t) + 255) & ~(size_t)255;
+  return enc + 2 * BH;
+}
+
+// Cross-encoder score: generic encoder -> hidden state of token 0 (<s>) -> dense + tanh -> out_proj
+// (XLMRobertaForSequenceClassification's RobertaClassificationHead with num_labels = 1).
+int sskd_teacher_score(const sskd_generic_config* cfg, const sskd_generic_weights* w, const void* d_head_dense_w,
+                       const float* d_head_dense_b, const void* d_head_out_w, const float* d_head_out_b,
+                       const int32_t* d_ids, const int32_t* d_mask, int B, int S, float* d_logits, void* d_workspace,
+                       size_t workspace_bytes, void* stream) {
+  Dims d{};
+  std::vector<LayerSaved> layers;
+  Saved sv{};
+  const size_t enc_bytes = cfg ? sskd_generic_workspace_bytes(cfg, B, S, 0) : 0;
+  const size_t need = cfg ? sskd_teacher_workspace_bytes(cfg, B, S) : 0;
+  if (B > 0 && (!d_workspace || workspace_bytes < need))
+    return sskd::fail(SSKD_ERR_WORKSPACE, "teacher_score: workspace %zu B < required %zu B", workspace_bytes, need);
+  int rc = prepare(cfg, w, B, S, 0, d_workspace, enc_bytes, &d, &layers, &sv);
+  if (rc != SSKD_OK || B == 0) return rc;
+  SSKD_REQUIRE(d_head_dense_w && d_head_dense_b && d_head_out_w && d_head_out_b && d_ids && d_mask && d_logits,
+               "teacher_score: null pointer");
+  hipStream_t st = sskd::as_stream(stream);
+  const bf16_t* fin = nullptr;
+  TRY(forward_all(cfg, w, d, d_ids, d_mask, sv, st, &fin));
+  const size_t BH = ((size_t)(B > 32 ? B : 32) * d.H * sizeof(bf16_t) + 255) & ~(size_t)255;
+  bf16_t* cls = reinterpret_cast<bf16_t*>(static_cast<char*>(d_workspace) + enc_bytes);
+  bf16_t* hid = reinterpret_cast<bf16_t*>(static_cast<char*>(d_workspace) + enc_bytes + BH);
+  hipLaunchKernelGGL(gather_first_token_kernel, dim3(B), dim3(256), 0, st, fin, S, d.H, cls);
+  TRY(sskd::check_launch("gather_first_token_kernel"));
+  TRY(gemm(cls, d.H, static_cast<const bf16_t*>(d_head_dense_w), d.H, hid, d.H, B, d.H, d.H, d_head_dense_b, false, false, st));
+  TRY(launch_tanh_fwd(hid, (int64_t)B * d.H, st));
+  return gemm(hid, d.H, static_cast<const bf16_t*>(d_head_out_w), d.H, d_logits, 1, B, 1, d.H, d_head_out_b, true, false, st);
 }
 
 // test hook: the NT GEMM by itself

@@ -12,6 +12,7 @@ outside the compute path and are not re-implemented here; they can be mounted in
 from __future__ import annotations
 
 import json
+import logging
 import os
 import time
 from contextlib import asynccontextmanager
@@ -22,7 +23,9 @@ from typing import Any, Dict, List, Optional
 from fastapi import FastAPI, HTTPException, Request, status
 from fastapi.responses import JSONResponse
 
-from ..index import FAISSIndexBuilder
+logger = logging.getLogger("semantic_search_kd_amd.serve")
+
+from ..index import FAISSIndexBuilder  # noqa: E402
 from ..student import StudentModel
 from .schemas import (
     EncodeRequest,
@@ -101,7 +104,6 @@ def create_app(
     settings: Optional[ServeSettings] = None,
 ) -> FastAPI:
     """Application factory with the reference's signature (app.py:124-130)."""
-    del teacher_model_path  # the cross-encoder teacher is outside this path; inject app_state.teacher to rerank
     settings = settings or ServeSettings.from_env()
     if student_model_path:
         settings.student_model_name = student_model_path
@@ -115,6 +117,14 @@ def create_app(
         app_state.settings = settings
         if app_state.student is None:
             app_state.student = StudentModel(model_name=settings.student_model_name, device=settings.student_device)
+        if teacher_model_path and app_state.teacher is None:
+            # reference: app.py:96-107 - a teacher that fails to load only disables reranking
+            try:
+                from ..teacher import TeacherModel
+
+                app_state.teacher = TeacherModel(model_name=teacher_model_path, device=settings.student_device)
+            except Exception as exc:  # noqa: BLE001
+                logger.warning("Failed to load teacher model (reranking disabled): %s", exc)
         if settings.index_dir and app_state.index_builder is None and Path(settings.index_dir).exists():
             _load_index_dir(Path(settings.index_dir))
         app_state.ready = True

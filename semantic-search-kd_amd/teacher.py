@@ -1,0 +1,265 @@
+"""``TeacherModel`` - the reference's cross-encoder reranker, on the MI355X generic encoder.
+
+``src/models/teacher.py`` is absent from the reference checkout; the surface below is reconstructed
+from its call sites:
+
+* ``TeacherModel(model_name="BAAI/bge-reranker-large", device=...)`` - src/serve/app.py:101-104,
+  scripts/evaluate_production.py:182
+* ``score(pairs, batch_size=32) -> sequence of float``; pairs are ``[q, d]`` lists or ``(q, d)``
+  tuples - src/serve/app.py:325-326, src/mining/miners.py:135-137
+* ``get_confidence(score) -> float in [0, 1]`` - src/mining/miners.py:148
+* ``predict_score(q, d) -> float`` - scripts/evaluate_production.py:73; ``predict`` alias - tests/conftest.py:108
+
+The model is ``XLMRobertaForSequenceClassification`` with one label (XLM-R-large: 24 layers, hidden
+1024, 16 heads, FFN 4096 - docs/adr-002): encoder -> <s> hidden state -> dense + tanh -> out_proj.
+``score`` returns the RAW logit (what the KD losses soften with a temperature) and ``get_confidence``
+its sigmoid - the reference's choice is unpinned (its source is missing); INTEGRATION.md notes it.
+Pure data parallel across GPUs: every rank scores its own slice of the pairs, no communication.
+"""
+from __future__ import annotations
+
+import json
+import math
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _native
+from .weights import BertConfig, synthetic_state_dict, synthetic_tensor
+
+
+@dataclass(frozen=True)
+class TeacherConfig:
+    """XLM-R-large defaults (bge-reranker-large): docs/adr-002, SURVEY.md section 8(f) rank 3."""
+
+    vocab_size: int = 250002
+    hidden_size: int = 1024
+    num_hidden_layers: int = 24
+    num_attention_heads: int = 16
+    intermediate_size: int = 4096
+    max_position_embeddings: int = 514
+    type_vocab_size: int = 1
+    layer_norm_eps: float = 1e-5
+    pad_token_id: int = 1
+
+    @staticmethod
+    def from_json(path: Path) -> "TeacherConfig":
+        raw = json.loads(Path(path).read_text())
+        keys = TeacherConfig.__dataclass_fields__.keys()
+        return TeacherConfig(**{k: raw[k] for k in keys if k in raw})
+
+    def as_bert(self) -> BertConfig:
+        return BertConfig(vocab_size=self.vocab_size, hidden_size=self.hidden_size,
+                          num_hidden_layers=self.num_hidden_layers, num_attention_heads=self.num_attention_heads,
+                          intermediate_size=self.intermediate_size, max_position_embeddings=self.max_position_embeddings,
+                          type_vocab_size=self.type_vocab_size, layer_norm_eps=self.layer_norm_eps)
+
+
+def synthetic_teacher_state_dict(cfg: TeacherConfig) -> Dict[str, np.ndarray]:
+    """Deterministic random-init weights (the recipe of weights.synthetic_state_dict) + classifier head."""
+    sd = synthetic_state_dict(cfg.as_bert())
+    h = cfg.hidden_size
+    # head scales chosen so that logits of different inputs differ at O(0.1 - 1) (a parity test needs that)
+    sd["classifier.dense.weight"] = synthetic_tensor("classifier.dense.weight", (h, h), 4.0 / math.sqrt(h))
+    sd["classifier.dense.bias"] = synthetic_tensor("classifier.dense.bias", (h,), 0.1)
+    sd["classifier.out_proj.weight"] = synthetic_tensor("classifier.out_proj.weight", (1, h), 8.0 / math.sqrt(h))
+    sd["classifier.out_proj.bias"] = synthetic_tensor("classifier.out_proj.bias", (1,), 0.1)
+    return sd
+
+
+class TeacherModel:
+    def __init__(self, model_name: str = "BAAI/bge-reranker-large", device: Optional[str] = None, *,
+                 config: Optional[TeacherConfig] = None, state_dict: Optional[Dict[str, np.ndarray]] = None,
+                 tokenizer=None, max_length: int = 512) -> None:
+        _native.require_gpu()
+        if device is None or device == "cuda":
+            self.torch_device = torch.device("cuda", torch.cuda.current_device())
+        else:
+            self.torch_device = torch.device(device)
+            if self.torch_device.type != "cuda":
+                raise RuntimeError(f"device={device!r}: the teacher runs on MI355X only (no CPU path)")
+        self.device = str(self.torch_device)
+        self.model_name = model_name
+        if state_dict is None:
+            mdir = Path(model_name)
+            if not mdir.is_dir():
+                raise FileNotFoundError(
+                    f"{model_name!r} is not a local directory. This backend never downloads checkpoints: point it at "
+                    "a directory holding config.json + model.safetensors + tokenizer.json"
+                )
+            from safetensors.numpy import load_file
+
+            config = TeacherConfig.from_json(mdir / "config.json")
+            raw = load_file(str(mdir / "model.safetensors"))
+            state_dict = {(k[8:] if k.startswith("roberta.") else k): np.asarray(v, np.float32) for k, v in raw.items()}
+            if tokenizer is None and (mdir / "tokenizer.json").exists():
+                from tokenizers import Tokenizer
+
+                tokenizer = Tokenizer.from_file(str(mdir / "tokenizer.json"))
+        self.config = config or TeacherConfig()
+        self.tokenizer = tokenizer
+        self.max_length = min(max_length, self.config.max_position_embeddings - 2)
+        self._upload(state_dict)
+        self._workspace: Optional[torch.Tensor] = None
+
+    @classmethod
+    def from_synthetic(cls, config: Optional[TeacherConfig] = None, device: Optional[str] = None, **kw) -> "TeacherModel":
+        cfg = config or TeacherConfig()
+        return cls("synthetic-reranker", device, config=cfg, state_dict=synthetic_teacher_state_dict(cfg), **kw)
+
+    @classmethod
+    def from_random_device(cls, config: Optional[TeacherConfig] = None, device: Optional[str] = None, seed: int = 0):
+        """Random-init weights drawn ON the device (benchmarks: the numpy recipe takes a minute for 560 M parameters)."""
+        cfg = config or TeacherConfig()
+        self = cls.__new__(cls)
+        _native.require_gpu()
+        self.torch_device = torch.device(device or f"cuda:{torch.cuda.current_device()}")
+        self.device, self.model_name, self.config, self.tokenizer = str(self.torch_device), "random-reranker", cfg, None
+        self.max_length = cfg.max_position_embeddings - 2
+        g = torch.Generator(device=self.torch_device).manual_seed(seed)
+        h, f = cfg.hidden_size, cfg.intermediate_size
+
+        def mat(*shape):
+            return (torch.randn(shape, generator=g, device=self.torch_device) * 0.02)
+
+        sd = {"embeddings.word_embeddings.weight": mat(cfg.vocab_size, h),
+              "embeddings.position_embeddings.weight": mat(cfg.max_position_embeddings, h),
+              "embeddings.token_type_embeddings.weight": mat(cfg.type_vocab_size, h),
+              "embeddings.LayerNorm.weight": torch.ones(h, device=self.torch_device),
+              "embeddings.LayerNorm.bias": torch.zeros(h, device=self.torch_device)}
+        for i in range(cfg.num_hidden_layers):
+            p = f"encoder.layer.{i}."
+            for nm, shape in (("attention.self.query", (h, h)), ("attention.self.key", (h, h)), ("attention.self.value", (h, h)),
+                              ("attention.output.dense", (h, h)), ("intermediate.dense", (f, h)), ("output.dense", (h, f))):
+                sd[p + nm + ".weight"] = mat(*shape)
+                sd[p + nm + ".bias"] = torch.zeros(shape[0], device=self.torch_device)
+            for nm in ("attention.output.LayerNorm", "output.LayerNorm"):
+                sd[p + nm + ".weight"] = torch.ones(h, device=self.torch_device)
+                sd[p + nm + ".bias"] = torch.zeros(h, device=self.torch_device)
+        sd["classifier.dense.weight"], sd["classifier.dense.bias"] = mat(h, h), torch.zeros(h, device=self.torch_device)
+        sd["classifier.out_proj.weight"], sd["classifier.out_proj.bias"] = mat(1, h), torch.zeros(1, device=self.torch_device)
+        self._upload(sd)
+        self._workspace = None
+        return self
+
+    # ------------------------------------------------------------------ weights
+    def _upload(self, sd) -> None:
+        cfg, dev = self.config, self.torch_device
+        keep = []
+
+        def t(x):
+            return x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x, np.float32))
+
+        def bf(x) -> int:
+            y = t(x).to(dev).to(torch.bfloat16).contiguous()
+            keep.append(y)
+            return y.data_ptr()
+
+        def f32(x) -> int:
+            y = t(x).to(device=dev, dtype=torch.float32).contiguous()
+            keep.append(y)
+            return y.data_ptr()
+
+        L = cfg.num_hidden_layers
+        layers = (_native.GenericLayerWeights * max(L, 1))()
+        for i in range(L):
+            p = f"encoder.layer.{i}."
+            lw = layers[i]
+            lw.wqkv = bf(torch.cat([t(sd[p + f"attention.self.{n}.weight"]) for n in ("query", "key", "value")], dim=0))
+            lw.bqkv = f32(torch.cat([t(sd[p + f"attention.self.{n}.bias"]) for n in ("query", "key", "value")]))
+            lw.wo, lw.bo = bf(sd[p + "attention.output.dense.weight"]), f32(sd[p + "attention.output.dense.bias"])
+            lw.w1, lw.b1 = bf(sd[p + "intermediate.dense.weight"]), f32(sd[p + "intermediate.dense.bias"])
+            lw.w2, lw.b2 = bf(sd[p + "output.dense.weight"]), f32(sd[p + "output.dense.bias"])
+            lw.ln1_g, lw.ln1_b = f32(sd[p + "attention.output.LayerNorm.weight"]), f32(sd[p + "attention.output.LayerNorm.bias"])
+            lw.ln2_g, lw.ln2_b = f32(sd[p + "output.LayerNorm.weight"]), f32(sd[p + "output.LayerNorm.bias"])
+        w = _native.GenericWeights()
+        w.word_emb = bf(sd["embeddings.word_embeddings.weight"])
+        w.pos_emb = bf(sd["embeddings.position_embeddings.weight"])
+        w.type_emb = bf(sd["embeddings.token_type_embeddings.weight"])
+        w.emb_ln_g, w.emb_ln_b = f32(sd["embeddings.LayerNorm.weight"]), f32(sd["embeddings.LayerNorm.bias"])
+        w.layers = layers
+        self._head = (bf(sd["classifier.dense.weight"]), f32(sd["classifier.dense.bias"]),
+                      bf(sd["classifier.out_proj.weight"]), f32(sd["classifier.out_proj.bias"]))
+        self._w, self._layers, self._keep = w, layers, keep
+        self._cfg = _native.GenericConfig(cfg.vocab_size, cfg.hidden_size, L, cfg.num_attention_heads, cfg.intermediate_size,
+                                          cfg.max_position_embeddings, cfg.type_vocab_size, float(cfg.layer_norm_eps),
+                                          cfg.pad_token_id + 1)
+
+    # ------------------------------------------------------------------ scoring
+    def score_token_ids(self, input_ids, attention_mask, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Raw logits fp32 ``[B]`` (device) for pre-tokenised pair sequences ``<s> q </s></s> d </s>``
+        (right-padded with ``pad_token_id``).  Enqueued on the current stream."""
+        lib = _native.load()
+        ids = torch.as_tensor(input_ids).to(device=self.torch_device, dtype=torch.int32)
+        mask = torch.as_tensor(attention_mask).to(device=self.torch_device, dtype=torch.int32)
+        B, S = ids.shape
+        Sp = max(32, -(-S // 32) * 32)
+        if Sp != S:
+            ids = torch.nn.functional.pad(ids, (0, Sp - S), value=self.config.pad_token_id)
+            mask = torch.nn.functional.pad(mask, (0, Sp - S))
+        ids, mask = ids.contiguous(), mask.contiguous()
+        if out is None:
+            out = torch.empty(B, dtype=torch.float32, device=self.torch_device)
+        if B == 0:
+            return out
+        need = int(lib.sskd_teacher_workspace_bytes(self._cfg, B, Sp))
+        if self._workspace is None or self._workspace.numel() < need:
+            self._workspace = None
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=self.torch_device)
+        with torch.cuda.device(self.torch_device):
+            _native.check(lib.sskd_teacher_score(
+                self._cfg, self._w, *self._head, ids.data_ptr(), mask.data_ptr(), B, Sp, out.data_ptr(),
+                self._workspace.data_ptr(), self._workspace.numel(),
+                int(torch.cuda.current_stream(self.torch_device).cuda_stream)))
+        return out
+
+    def tokenize_pairs(self, pairs: Sequence[Union[Tuple[str, str], List[str]]]):
+        if self.tokenizer is None:
+            raise RuntimeError("no tokenizer: the model directory has no tokenizer.json (use score_token_ids)")
+        encs = self.tokenizer.encode_batch([(p[0], p[1]) for p in pairs])
+        rows = [e.ids[: self.max_length - 1] + e.ids[-1:] if len(e.ids) > self.max_length else e.ids for e in encs]
+        width = max((len(r) for r in rows), default=1)
+        ids = np.full((len(rows), width), self.config.pad_token_id, np.int32)
+        mask = np.zeros((len(rows), width), np.int32)
+        for i, r in enumerate(rows):
+            ids[i, : len(r)] = r
+            mask[i, : len(r)] = 1
+        return ids, mask
+
+    def score(self, pairs: Sequence[Union[Tuple[str, str], List[str]]], batch_size: int = 32) -> List[float]:
+        """``CrossEncoder.predict``-shaped: one float (raw logit) per (query, passage) pair.  Pairs are
+        sorted by length and cut into launches by a token budget; ``batch_size`` (reference default 32)
+        does not shape the GPU work."""
+        del batch_size
+        n = len(pairs)
+        if n == 0:
+            return []
+        ids, mask = self.tokenize_pairs(pairs)
+        lengths = mask.sum(1)
+        order = np.argsort(-lengths, kind="stable")
+        out = torch.empty(n, dtype=torch.float32, device=self.torch_device)
+        budget = 64 * 512
+        lo = 0
+        while lo < n:
+            width = max(int(lengths[order[lo]]), 1)
+            rows = max(1, budget // (-(-width // 32) * 32))
+            idx = order[lo : lo + rows]
+            out[torch.from_numpy(idx).to(self.torch_device)] = self.score_token_ids(ids[idx, :width], mask[idx, :width])
+            lo += rows
+        return [float(x) for x in out.cpu().numpy()]
+
+    def predict_score(self, query: str, document: str) -> float:
+        return self.score([(query, document)])[0]
+
+    def predict(self, pairs, batch_size: int = 32):
+        return np.asarray(self.score(pairs, batch_size=batch_size), np.float32)
+
+    @staticmethod
+    def get_confidence(score: float) -> float:
+        return 1.0 / (1.0 + math.exp(-float(score)))
+
+    def cleanup(self) -> None:
+        self._workspace = None

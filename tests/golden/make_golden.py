@@ -404,6 +404,53 @@ def make_bert_grads():
     print(f"[bert_grads_small] {len(hf_grads)} parameter tensors, oracle autograd == transformers autograd")
 
 
+TEACHER_SMALL = dict(vocab_size=800, hidden_size=128, num_hidden_layers=3, num_attention_heads=2, intermediate_size=512,
+                     max_position_embeddings=130)
+
+
+def teacher_case():
+    from semantic_search_kd_amd.teacher import TeacherConfig, synthetic_teacher_state_dict
+
+    cfg = TeacherConfig(**TEACHER_SMALL)
+    sd = synthetic_teacher_state_dict(cfg)
+    lengths = [96, 70, 33, 12, 5]
+    ids, mask = enc_oracle.synthetic_token_ids(5, 96, seed=51, vocab=cfg.vocab_size, lengths=lengths)
+    ids = np.where(mask == 1, np.maximum(ids, 4), cfg.pad_token_id).astype(np.int32)  # XLM-R: <s>=0, <pad>=1, </s>=2
+    ids[:, 0] = 0
+    for b, n in enumerate(lengths):
+        ids[b, n - 1] = 2
+    return cfg, sd, ids, mask
+
+
+def make_xlmr():
+    """Logits of ``transformers.XLMRobertaForSequenceClassification`` (num_labels = 1: the architecture
+    of the reference's bge-reranker-large teacher) built from an in-memory config on synthetic weights;
+    the oracle restatement (oracle/teacher.py) is asserted equal here."""
+    from transformers import XLMRobertaConfig, XLMRobertaForSequenceClassification
+
+    from oracle import teacher as teacher_oracle
+
+    cfg, sd, ids, mask = teacher_case()
+    hf_cfg = XLMRobertaConfig(
+        vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+        num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+        max_position_embeddings=cfg.max_position_embeddings, type_vocab_size=cfg.type_vocab_size,
+        layer_norm_eps=cfg.layer_norm_eps, hidden_act="gelu", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+        classifier_dropout=0.0, num_labels=1, pad_token_id=cfg.pad_token_id, bos_token_id=0, eos_token_id=2,
+    )
+    model = XLMRobertaForSequenceClassification(hf_cfg).eval()
+    hf_sd = {("roberta." + k if not k.startswith("classifier.") else k): torch.from_numpy(v) for k, v in sd.items()}
+    missing, unexpected = model.load_state_dict(hf_sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("position_ids" in m for m in missing), missing
+    with torch.no_grad():
+        want = model(input_ids=torch.from_numpy(ids).long(), attention_mask=torch.from_numpy(mask).long()).logits[:, 0].numpy()
+    got = teacher_oracle.logits(sd, ids, mask, cfg.num_hidden_layers, cfg.num_attention_heads, cfg.layer_norm_eps, cfg.pad_token_id)
+    print(f"[xlmr_small] oracle vs transformers logits: max |diff| = {np.abs(got - want).max():.3e}; logits {want}")
+    assert np.abs(got - want).max() < 1e-5
+    np.savez_compressed(HERE / "xlmr_small.npz", input_ids=ids, attention_mask=mask, logits=want)
+
+
 def make_kd_loss():
     """Losses and autograd gradients from the REFERENCE'S OWN code (src/kd/losses.py), imported from
     /root/reference in this container only.  Its one missing dependency is a logging package used
@@ -504,6 +551,7 @@ if __name__ == "__main__":
     make_bert(2, "stress_l2", stress=True)
     make_bert(12, "stress_l12", stress=True)
     make_bert_grads()
+    make_xlmr()
     make_kd_loss()
     make_ance()
     make_api_schemas()
