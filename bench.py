@@ -383,14 +383,15 @@ def main() -> None:
                                           text=not args.no_text and rank == 0)
             if rank == 0 and world == 1 and not args.no_cpu_baseline:
                 line["encode"]["cpu_baseline"] = cpu_encode_baseline()
-        if not args.no_teacher:
-            from semantic_search_kd_amd.bench_support import bench_teacher
+    # ---- teacher cross-encoder (cfg 5 model, data parallel) and KD training step (cfg 4) -------
+    if not args.no_teacher:
+        from semantic_search_kd_amd.bench_support import bench_teacher
 
-            line["teacher"] = bench_teacher(dev, world, max(2, args.steps // 2), 1, barrier)
-        if rank == 0 and world == 1 and not args.no_train:
-            from semantic_search_kd_amd.bench_support import bench_kd_step
+        line["teacher"] = bench_teacher(dev, world, max(2, args.steps // 2), 1, barrier)
+    if rank == 0 and world == 1 and not args.no_train:
+        from semantic_search_kd_amd.bench_support import bench_kd_step
 
-            line["kd_step"] = bench_kd_step(dev)
+        line["kd_step"] = bench_kd_step(dev)
 
     # ---- CPU baseline: rank 0, N = 1 only --------------------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

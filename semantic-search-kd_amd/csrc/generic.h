@@ -23,6 +23,8 @@ struct GemmArgs {
   float alpha;
   int c_is_f32;        // 0: bf16 output, 1: fp32 output
   int accumulate;      // fp32 output only: C += result
+  int split_k;         // > 1 (unbatched, fp32 accumulate only): K is cut into split_k slices, one workgroup
+                       // layer each, partial products meet through fp32 atomics (order not reproducible)
 };
 
 int launch_gemm_nt(const GemmArgs& a, hipStream_t st);

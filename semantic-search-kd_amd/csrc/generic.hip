@@ -31,14 +31,23 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
   constexpr int LDT = BK + 8;
   constexpr int CPR = BK / 8;
   constexpr int NCH = 128 * CPR / 256;
-  __shared__ __attribute__((aligned(16))) bf16_t As[128 * LDT];
-  __shared__ __attribute__((aligned(16))) bf16_t Bs[128 * LDT];
+  constexpr int LDC = 128 + 8;  // staged output tile row (bf16 elements)
+  constexpr int LDS_ELEMS = 2 * 128 * LDT > 128 * LDC ? 2 * 128 * LDT : 128 * LDC;
+  __shared__ __attribute__((aligned(16))) bf16_t lds[LDS_ELEMS];
+  bf16_t* const As = lds;
+  bf16_t* const Bs = lds + 128 * LDT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int z = blockIdx.z, b1 = z / p.batch2, b2 = z - b1 * p.batch2;
-  const bf16_t* A = p.A + b1 * p.sA1 + b2 * p.sA2;
-  const bf16_t* B = p.B + b1 * p.sB1 + b2 * p.sB2;
+  const bool split = p.split_k > 1;
+  const int z = blockIdx.z, b1 = split ? 0 : z / p.batch2, b2 = split ? 0 : z - b1 * p.batch2;
+  const int nk_all = p.K / BK;
+  const int k_per = split ? (nk_all + p.split_k - 1) / p.split_k : nk_all;
+  const int kt0 = split ? z * k_per : 0;
+  const int nk = split ? max(0, min(k_per, nk_all - kt0)) : nk_all;
+  const bf16_t* A = p.A + b1 * p.sA1 + b2 * p.sA2 + (int64_t)kt0 * BK;
+  const bf16_t* B = p.B + b1 * p.sB1 + b2 * p.sB2 + (int64_t)kt0 * BK;
   const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+  if (nk == 0) return;
 
   u32x4 ra[NCH], rb[NCH];
   auto gload = [&](int kt) {
@@ -66,7 +75,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int nk = p.K / BK;
   gload(0);
   for (int kt = 0; kt < nk; ++kt) {
     sstore();
@@ -95,6 +103,39 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
   const int h = lane >> 5;
   char* Cb = static_cast<char*>(p.C);
   const int64_t cbase = b1 * p.sC1 + b2 * p.sC2;
+  if (!p.c_is_f32) {
+    // bf16 output: the tile meets in LDS (the operand buffers are dead) and leaves in 16-byte row
+    // segments instead of 64 two-byte stores per lane
+    bf16_t* const Ct = lds;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int nl = wn * 64 + j * 32 + (lane & 31);
+        const int n = n0 + nl;
+        const float bias = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            Ct[(wm * 64 + i * 32 + 8 * g + 4 * h + e) * LDC + nl] = (bf16_t)(p.alpha * acc[i][j][4 * g + e] + bias);
+      }
+    __syncthreads();
+    bf16_t* Cg = reinterpret_cast<bf16_t*>(Cb) + cbase;
+    const bool vec_ok = (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(Cg) & 15) == 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 4, c8 = (idx & 15) * 8;
+      const int m = m0 + row, n = n0 + c8;
+      if (m >= p.M || n >= p.N) continue;
+      if (vec_ok && n + 8 <= p.N) {
+        *reinterpret_cast<u32x4*>(Cg + (int64_t)m * p.ldc + n) = *reinterpret_cast<const u32x4*>(Ct + row * LDC + c8);
+      } else {
+        for (int e = 0; e < 8 && n + e < p.N; ++e) Cg[(int64_t)m * p.ldc + n + e] = Ct[row * LDC + c8 + e];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -110,7 +151,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
           if (m >= p.M) continue;
           const float v = p.alpha * acc[i][j][4 * g + e] + bias;
           const int64_t off = cbase + (int64_t)m * p.ldc + n;
-          if (p.c_is_f32) {
+          if (split) {
+            atomicAdd(reinterpret_cast<float*>(Cb) + off, v);
+          } else if (p.c_is_f32) {
             float* c = reinterpret_cast<float*>(Cb) + off;
             *c = p.accumulate ? *c + v : v;
           } else {
@@ -120,23 +163,39 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
     }
 }
 
+// 64 x 64 tiles through LDS; both the loads and the stores move 8 bytes per thread in 128-byte row
+// segments (R, C, leading dimensions and batch strides are multiples of 4 on this path)
 __global__ __launch_bounds__(256) void transpose_kernel(TransposeArgs p) {
-  __shared__ unsigned short tile[32][33];
+  __shared__ unsigned short tile[64][66];
   const int z = blockIdx.z, b1 = z / p.batch2, b2 = z - b1 * p.batch2;
   const unsigned short* in = reinterpret_cast<const unsigned short*>(p.in) + b1 * p.sI1 + b2 * p.sI2;
   unsigned short* out = reinterpret_cast<unsigned short*>(p.out) + b1 * p.sO1 + b2 * p.sO2;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int r = r0 + ty + 8 * i, c = c0 + tx;
-    tile[ty + 8 * i][tx] = (r < p.R && c < p.C) ? in[(int64_t)r * p.ld_in + c] : (unsigned short)0;
+    const int r = r0 + ty + 16 * i, c = c0 + tx * 4;
+    unsigned int lo = 0, hi = 0;
+    if (r < p.R && c < p.C) {  // C % 4 == 0: the four columns are valid together
+      const uint2 v = *reinterpret_cast<const uint2*>(in + (int64_t)r * p.ld_in + c);
+      lo = v.x;
+      hi = v.y;
+    }
+    unsigned int* dst = reinterpret_cast<unsigned int*>(&tile[ty + 16 * i][tx * 4]);
+    dst[0] = lo;
+    dst[1] = hi;
   }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int c = c0 + ty + 8 * i, r = r0 + tx;
-    if (c < p.C && r < p.R) out[(int64_t)c * p.ld_out + r] = tile[tx][ty + 8 * i];
+    const int c = c0 + ty + 16 * i, r = r0 + tx * 4;
+    if (c < p.C && r < p.R) {
+      const int lc = ty + 16 * i, lr = tx * 4;
+      uint2 v;
+      v.x = (unsigned int)tile[lr][lc] | ((unsigned int)tile[lr + 1][lc] << 16);
+      v.y = (unsigned int)tile[lr + 2][lc] | ((unsigned int)tile[lr + 3][lc] << 16);
+      *reinterpret_cast<uint2*>(out + (int64_t)c * p.ld_out + r) = v;
+    }
   }
 }
 
@@ -286,6 +345,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 // ------------------------------------------------------------------------- //
 // softmax over rows of S <= 512 scores, one wave per row
 // ------------------------------------------------------------------------- //
+typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(bf16_t* __restrict__ sc, const int32_t* __restrict__ key_mask,
                                                           int64_t rows, int heads, int S, float scale) {
   const int lane = threadIdx.x & 63;
@@ -293,28 +354,44 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(bf16_t* __restrict__ s
   if (row >= rows) return;
   const int64_t b = row / ((int64_t)heads * S);
   bf16_t* p = sc + row * S;
-  float v[8];
+  float v[2][4];
   float mx = -INFINITY;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int j = lane + 64 * i;
-    v[i] = -INFINITY;
-    if (j < S && key_mask[b * S + j] != 0) v[i] = (float)p[j] * scale;
-    mx = fmaxf(mx, v[i]);
+  for (int i = 0; i < 2; ++i) {
+    const int j = (lane + 64 * i) * 4;  // S % 4 == 0: four keys are valid together
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[i][e] = -INFINITY;
+    if (j < S) {
+      const bf16x4v x = *reinterpret_cast<const bf16x4v*>(p + j);
+      const int4 km = *reinterpret_cast<const int4*>(key_mask + b * S + j);
+      const int k[4] = {km.x, km.y, km.z, km.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (k[e] != 0) v[i][e] = (float)x[e] * scale;
+        mx = fmaxf(mx, v[i][e]);
+      }
+    }
   }
   mx = wave_max(mx);
   float sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    v[i] = mx == -INFINITY ? 0.f : __expf(v[i] - mx);
-    sum += v[i];
-  }
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[i][e] = mx == -INFINITY ? 0.f : __expf(v[i][e] - mx);
+      sum += v[i][e];
+    }
   sum = wave_sum(sum);
   const float inv = sum > 0.f ? 1.0f / sum : 0.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int j = lane + 64 * i;
-    if (j < S) p[j] = (bf16_t)(v[i] * inv);
+  for (int i = 0; i < 2; ++i) {
+    const int j = (lane + 64 * i) * 4;
+    if (j < S) {
+      bf16x4v o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(v[i][e] * inv);
+      *reinterpret_cast<bf16x4v*>(p + j) = o;
+    }
   }
 }
 
@@ -325,20 +402,34 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(bf16_t* __restrict__ d
   if (row >= rows) return;
   bf16_t* d = dP + row * S;
   const bf16_t* p = P + row * S;
-  float dv[8], pv[8];
+  float dv[2][4], pv[2][4];
   float dot = 0.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int j = lane + 64 * i;
-    dv[i] = j < S ? (float)d[j] : 0.f;
-    pv[i] = j < S ? (float)p[j] : 0.f;
-    dot += dv[i] * pv[i];
+  for (int i = 0; i < 2; ++i) {
+    const int j = (lane + 64 * i) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dv[i][e] = pv[i][e] = 0.f;
+    if (j < S) {
+      const bf16x4v a = *reinterpret_cast<const bf16x4v*>(d + j);
+      const bf16x4v b = *reinterpret_cast<const bf16x4v*>(p + j);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        dv[i][e] = (float)a[e];
+        pv[i][e] = (float)b[e];
+        dot += dv[i][e] * pv[i][e];
+      }
+    }
   }
   dot = wave_sum(dot);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int j = lane + 64 * i;
-    if (j < S) d[j] = (bf16_t)(scale * pv[i] * (dv[i] - dot));
+  for (int i = 0; i < 2; ++i) {
+    const int j = (lane + 64 * i) * 4;
+    if (j < S) {
+      bf16x4v o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(scale * pv[i][e] * (dv[i][e] - dot));
+      *reinterpret_cast<bf16x4v*>(d + j) = o;
+    }
   }
 }
 
@@ -388,16 +479,23 @@ __global__ __launch_bounds__(256) void add_kernel(const bf16_t* __restrict__ a, 
   }
 }
 
-constexpr int COLSUM_ROWS = 256;
+constexpr int COLSUM_ROWS = 64;
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+// thread = one column PAIR (4-byte loads, 256 B per wave-instruction), slab of COLSUM_ROWS rows
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ dY, int64_t M, int N, int64_t ld,
                                                      float* __restrict__ db) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 2;
   if (c >= N) return;
   const int64_t r0 = (int64_t)blockIdx.y * COLSUM_ROWS;
   const int64_t r1 = r0 + COLSUM_ROWS < M ? r0 + COLSUM_ROWS : M;
-  float s = 0.f;
-  for (int64_t r = r0; r < r1; ++r) s += (float)dY[r * ld + c];
-  atomicAdd(db + c, s);
+  float s0 = 0.f, s1 = 0.f;
+  for (int64_t r = r0; r < r1; ++r) {
+    const bf16x2v v = *reinterpret_cast<const bf16x2v*>(dY + r * ld + c);
+    s0 += (float)v[0];
+    s1 += (float)v[1];
+  }
+  atomicAdd(db + c, s0);
+  atomicAdd(db + c + 1, s1);
 }
 
 // ------------------------------------------------------------------------- //
@@ -544,7 +642,10 @@ int launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
   SSKD_REQUIRE((reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 15) == 0,
                "gemm_nt: operands must be 16-byte aligned");
   SSKD_REQUIRE(!a.accumulate || a.c_is_f32, "gemm_nt: accumulate needs an fp32 output");
-  const dim3 grid((unsigned)sskd::ceil_div(a.N, 128), (unsigned)sskd::ceil_div(a.M, 128), (unsigned)(a.batch1 * a.batch2));
+  SSKD_REQUIRE(a.split_k <= 1 || (a.accumulate && a.c_is_f32 && a.batch1 * a.batch2 == 1 && !a.bias),
+               "gemm_nt: split-K needs an unbatched fp32 accumulating output without bias");
+  const dim3 grid((unsigned)sskd::ceil_div(a.N, 128), (unsigned)sskd::ceil_div(a.M, 128),
+                  (unsigned)(a.split_k > 1 ? a.split_k : a.batch1 * a.batch2));
   if (a.K % 64 == 0) hipLaunchKernelGGL(gemm_nt_kernel<64>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(gemm_nt_kernel<32>, grid, dim3(256), 0, st, a);
   return sskd::check_launch("gemm_nt_kernel");
@@ -552,7 +653,10 @@ int launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
 
 int launch_transpose(const TransposeArgs& a, hipStream_t st) {
   if (a.R == 0 || a.C == 0) return SSKD_OK;
-  const dim3 grid((unsigned)sskd::ceil_div(a.C, 32), (unsigned)sskd::ceil_div(a.R, 32), (unsigned)(a.batch1 * a.batch2));
+  SSKD_REQUIRE(a.R % 4 == 0 && a.C % 4 == 0 && a.ld_in % 4 == 0 && a.ld_out % 4 == 0 && a.sI1 % 4 == 0 && a.sI2 % 4 == 0 &&
+                   a.sO1 % 4 == 0 && a.sO2 % 4 == 0,
+               "transpose: shapes and strides must be multiples of 4");
+  const dim3 grid((unsigned)sskd::ceil_div(a.C, 64), (unsigned)sskd::ceil_div(a.R, 64), (unsigned)(a.batch1 * a.batch2));
   hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, st, a);
   return sskd::check_launch("transpose_kernel");
 }
@@ -576,7 +680,7 @@ int launch_ln_bwd(const bf16_t* dy, const bf16_t* z, const float* mean, const fl
 }
 
 int launch_softmax_fwd(bf16_t* scores, const int32_t* key_mask, int B, int heads, int S, float scale, hipStream_t st) {
-  SSKD_REQUIRE(S >= 1 && S <= 512, "softmax: S=%d outside [1, 512]", S);
+  SSKD_REQUIRE(S >= 4 && S <= 512 && S % 4 == 0, "softmax: S=%d must be a multiple of 4 in [4, 512]", S);
   const int64_t rows = (int64_t)B * heads * S;
   if (rows == 0) return SSKD_OK;
   hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)sskd::ceil_div(rows, 4)), dim3(256), 0, st, scores, key_mask,
@@ -585,7 +689,7 @@ int launch_softmax_fwd(bf16_t* scores, const int32_t* key_mask, int B, int heads
 }
 
 int launch_softmax_bwd(bf16_t* dP, const bf16_t* P, int64_t rows, int S, float scale, hipStream_t st) {
-  SSKD_REQUIRE(S >= 1 && S <= 512, "softmax: S=%d outside [1, 512]", S);
+  SSKD_REQUIRE(S >= 4 && S <= 512 && S % 4 == 0, "softmax: S=%d must be a multiple of 4 in [4, 512]", S);
   if (rows == 0) return SSKD_OK;
   hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)sskd::ceil_div(rows, 4)), dim3(256), 0, st, dP, P, rows, S, scale);
   return sskd::check_launch("softmax_bwd_kernel");
@@ -613,7 +717,8 @@ int launch_tanh_fwd(bf16_t* x, int64_t n, hipStream_t st) {
 
 int launch_colsum(const bf16_t* dY, int64_t M, int N, int64_t ld, float* db, hipStream_t st) {
   if (M == 0 || N == 0) return SSKD_OK;
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)sskd::ceil_div(N, 256), (unsigned)sskd::ceil_div(M, COLSUM_ROWS)),
+  SSKD_REQUIRE(N % 2 == 0 && ld % 2 == 0, "colsum: N and ld must be even");
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)sskd::ceil_div(N, 512), (unsigned)sskd::ceil_div(M, COLSUM_ROWS)),
                      dim3(256), 0, st, dY, M, N, ld, db);
   return sskd::check_launch("colsum_kernel");
 }

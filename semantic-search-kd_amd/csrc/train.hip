@@ -144,6 +144,15 @@ int gemm(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, in
   g.alpha = 1.0f;
   g.c_is_f32 = c_f32;
   g.accumulate = acc;
+  // weight-gradient products (few output tiles, K = every token of the step): cut K over enough
+  // workgroups to fill the chip; the slices meet through fp32 atomics
+  if (acc && c_f32 && !bias) {
+    const int64_t tiles = sskd::ceil_div(M, 128) * sskd::ceil_div(N, 128);
+    int split = (int)(1024 / (tiles > 0 ? tiles : 1));
+    const int max_split = K / 256;  // at least 256 of K per slice
+    if (split > max_split) split = max_split;
+    g.split_k = split > 1 ? split : 1;
+  }
   return launch_gemm_nt(g, st);
 }
 
