@@ -152,15 +152,20 @@ def test_e5_prefixes(mock_st):
 
 
 @patch("semantic_search_kd_amd.student.SentenceTransformer")
-def test_cleanup_is_safe_and_training_entry_is_refused(mock_st):
-    """reference tests/test_student_model.py:126-137, tests/test_hardening.py:432-453."""
-    mock_st.return_value = _mock_encoder()
+def test_cleanup_is_safe_and_training_entry_delegates_to_the_encoder(mock_st):
+    """reference tests/test_student_model.py:126-137, tests/test_hardening.py:432-453; the training entry
+    (src/kd/train.py:180-187) tokenises and hands ids / mask to the encoder's trainable module."""
+    enc = _mock_encoder()
+    mock_st.return_value = enc
     from semantic_search_kd_amd.student import StudentModel
 
     model = StudentModel(model_name="test-model", device="cpu")
     model.cleanup()
-    with pytest.raises(NotImplementedError):
-        model.encode_with_gradients(["x"])
+    enc.tokenize.return_value = {"input_ids": "IDS", "attention_mask": "MASK"}
+    out = model.encode_with_gradients("x", normalize=False)
+    enc.tokenize.assert_called_once_with(["x"])
+    enc.trainable.return_value.assert_called_once_with("IDS", "MASK", normalize=False)
+    assert out is enc.trainable.return_value.return_value
 
 
 def test_student_without_gpu_fails_loudly():
