@@ -38,6 +38,7 @@ K = 10
 DIM = 384
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TF = 157.3   # fp32-input MFMA peak (= vector rate)
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
 
 
 class HipEvents:
@@ -187,6 +188,8 @@ def main() -> None:
     ap.add_argument("--no-encode", action="store_true")
     ap.add_argument("--no-ragged", action="store_true", help="skip the ragged-length encode leg")
     ap.add_argument("--no-text", action="store_true", help="skip the text -> embedding leg")
+    ap.add_argument("--exact-scan", action="store_true",
+                    help="time the plain exact fp32 scan instead of the bf16-screened search (same results, bit for bit)")
     ap.add_argument("--no-train", action="store_true", help="skip the KD training-step leg (BASELINE cfg 4)")
     ap.add_argument("--no-teacher", action="store_true", help="skip the teacher cross-encoder leg (BASELINE cfg 5 model)")
     ap.add_argument("--launch-check", action="store_true",
@@ -257,6 +260,9 @@ def main() -> None:
 
     index = pkg.FAISSIndexBuilder(embedding_dim=DIM, index_type="HNSW", metric="ip", device=str(dev), id_offset=lo)
     index.add(shard)
+    screened_bytes = int(lib.sskd_index_search_screened_workspace_bytes(index.ntotal, nq, K))
+    use_screen = not args.exact_scan and screened_bytes > 0
+    index.screening = use_screen
     n_local = index.ntotal
     def local_search(q, k, out_scores=None, out_ids=None):
         return index.search_device(q, k, normalize_queries=False, out_scores=out_scores, out_ids=out_ids)
@@ -265,8 +271,11 @@ def main() -> None:
 
     # profiled variant of the local scan (events around the scan kernel, same stream)
     ev = HipEvents()
-    ws_bytes = int(lib.sskd_index_search_workspace_bytes(n_local, nq, K))
+    ws_bytes = screened_bytes if use_screen else int(lib.sskd_index_search_workspace_bytes(n_local, nq, K))
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    status = torch.zeros(2, dtype=torch.int32, device=dev)
+    if use_screen:
+        index.search_device(queries[:64], K, normalize_queries=False)  # builds the bf16 screening copy
     out_s = torch.empty((nq, K), dtype=torch.float32, device=dev)
     out_i = torch.empty((nq, K), dtype=torch.int64, device=dev)
     ev_pairs = [(ev.create(), ev.create()) for _ in range(args.steps)]
@@ -275,13 +284,21 @@ def main() -> None:
         a, b = ev_pairs[step]
         o_s = out_s if out_scores is None else out_scores
         o_i = out_i if out_ids is None else out_ids
-        _native.check(
-            lib.sskd_index_search_profiled(
-                index._tiled.data_ptr(), n_local, queries.data_ptr(), nq, K, lo,
-                o_s.data_ptr(), o_i.data_ptr(), ws.data_ptr(), ws.numel(),
-                int(torch.cuda.current_stream(dev).cuda_stream), a, b,
+        st_ptr = int(torch.cuda.current_stream(dev).cuda_stream)
+        if use_screen:
+            _native.check(
+                lib.sskd_index_search_screened(
+                    index._tiled.data_ptr(), index._bf16.data_ptr(), n_local, queries.data_ptr(), nq, K, lo,
+                    o_s.data_ptr(), o_i.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(), st_ptr, a, b,
+                )
             )
-        )
+        else:
+            _native.check(
+                lib.sskd_index_search_profiled(
+                    index._tiled.data_ptr(), n_local, queries.data_ptr(), nq, K, lo,
+                    o_s.data_ptr(), o_i.data_ptr(), ws.data_ptr(), ws.numel(), st_ptr, a, b,
+                )
+            )
         return o_s, o_i
 
     def barrier():
@@ -308,16 +325,27 @@ def main() -> None:
     qps = nq * args.steps / dt
 
     scan_ms = float(np.mean([ev.elapsed_ms(a, b) for a, b in ev_pairs]))
-    qpb, passes, slices, waves, scans = (C.c_int() for _ in range(5))
-    lib.sskd_index_search_plan(n_local, nq, K, qpb, passes, slices, waves, scans)
-    # algorithmic bytes of one scan launch: P passes x rows x 1536 B + queries + partial lists
-    alg_bytes = passes.value * n_local * DIM * 4 + nq * DIM * 4 + nq * K * 12
-    achieved_gbs = alg_bytes / (scan_ms * 1e-3) / 1e9
     flops = 2.0 * nq * n_local * DIM
+    traffic, traffic_from = None, None
+    if use_screen:
+        # screening kernel: bf16 MFMA (32x32x16) over a bf16 copy of the rows; B_q = 128 queries per workgroup
+        assert int(status[0].item()) == 0, "screened search overflowed its exact fallback"
+        qpb_v, passes_v = (128 if nq >= 256 else 64), -(-nq // (128 if nq >= 256 else 64))
+        slices_v = None
+        alg_bytes = passes_v * n_local * DIM * 2 + nq * DIM * 4 + nq * K * 12
+        kernel_name, peak_tf = "screen_topk_kernel", MFMA_BF16_PEAK_TF
+        tpath = REPO / "profiles" / "screen_traffic.json"
+    else:
+        qpb, passes, slices, waves, scans = (C.c_int() for _ in range(5))
+        lib.sskd_index_search_plan(n_local, nq, K, qpb, passes, slices, waves, scans)
+        qpb_v, passes_v, slices_v = qpb.value, passes.value, slices.value
+        # algorithmic bytes of one scan launch: P passes x rows x 1536 B + queries + partial lists
+        alg_bytes = passes_v * n_local * DIM * 4 + nq * DIM * 4 + nq * K * 12
+        kernel_name, peak_tf = "scan_topk_kernel", MFMA_F32_PEAK_TF
+        tpath = REPO / "profiles" / "scan_traffic.json"
+    achieved_gbs = alg_bytes / (scan_ms * 1e-3) / 1e9
     # HBM bytes per launch from the PMC counters: they cannot be read from inside this process, so the
     # number comes from the committed rocprofv3 --pmc passes of this same command and says so
-    traffic, traffic_from = None, None
-    tpath = REPO / "profiles" / "scan_traffic.json"
     if tpath.exists() and world == 1 and n == N_CORPUS and nq == N_QUERIES:
         try:
             tj = json.loads(tpath.read_text())
@@ -337,7 +365,7 @@ def main() -> None:
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if not use_screen else "bf16 screen + f32 exact",
         "data": "synthetic",
         "config": {
             "workload": f"cosine top-{K}: {nq} queries x {n} x {DIM}-d fp32 corpus in HBM (configs[1] search), "
@@ -345,9 +373,12 @@ def main() -> None:
             "corpus_rows": n,
             "queries": nq,
             "k": K,
-            "queries_per_block": qpb.value,
-            "corpus_passes": passes.value,
-            "slices": slices.value,
+            "queries_per_block": qpb_v,
+            "corpus_passes": passes_v,
+            "slices": slices_v,
+            "search_path": "bf16-screened + exact fp32 re-scoring (bit-identical to the exact scan)" if use_screen
+            else "exact fp32 scan",
+            "exact_fallback_queries": int(status[1].item()) if use_screen else 0,
         },
         # The scan is bound by the fp32 matrix pipe, not by HBM: with B_q = 64 queries per block its
         # MFMAs saturate at 4.9 TB/s of *algorithmic* corpus traffic, and the XCD-affine slice mapping
@@ -355,11 +386,11 @@ def main() -> None:
         # B_q-dependent algorithmic bytes of SURVEY.md §8(d) against the 8 TB/s HBM peak.
         "roofline": {
             "bound": "mfma",
-            "kernel": "scan_topk_kernel",
+            "kernel": kernel_name,
             "achieved": round(flops / (scan_ms * 1e-3) / 1e12, 2),
-            "peak": MFMA_F32_PEAK_TF,
+            "peak": peak_tf,
             "unit": "TFLOP/s",
-            "frac": round(flops / (scan_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
+            "frac": round(flops / (scan_ms * 1e-3) / 1e12 / peak_tf, 4),
             "traffic": traffic,
             "traffic_from": traffic_from,
             "kernel_ms": round(scan_ms, 4),

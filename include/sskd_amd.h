@@ -125,6 +125,24 @@ int sskd_index_search_profiled(const float* d_tiled, int64_t n_rows,
                                void* d_workspace, size_t workspace_bytes, void* stream,
                                void* ev_scan_begin, void* ev_scan_end);
 
+/* Screened search for batch shapes (k <= 10, nq >= 64, >= 2048 rows): a bf16-MFMA screening pass
+ * (16x the fp32 matrix rate) over a bf16 copy of the index, then exact fp32 re-scoring of the
+ * candidates inside a PROVED error band (|screen - exact| <= 0.0041 |q| max|row|, Cauchy-Schwarz on
+ * the bf16 rounding), so scores and ids are bit-identical to sskd_index_search's.  Queries whose
+ * candidate band cannot be proven complete (a per-lane list full inside the band: duplicate-heavy
+ * neighbourhoods) are answered by the exact scan inside the same call, up to 1024 of them.
+ * d_status (device int[2]): [0] = 0 ok, 1 = more than 1024 unproven queries - their output rows
+ * hold (NaN, -2) and the caller must re-run sskd_index_search; [1] = queries that took the exact
+ * fallback.  d_bf16: sskd_index_bf16_bytes(n_rows) bytes filled by sskd_index_make_bf16 from the
+ * CURRENT tiled index (re-make it after sskd_index_add_rows). */
+size_t sskd_index_bf16_bytes(int64_t n_rows);
+int sskd_index_make_bf16(const float* d_tiled, int64_t n_rows, void* d_bf16, void* stream);
+size_t sskd_index_search_screened_workspace_bytes(int64_t n_rows, int nq, int k);
+int sskd_index_search_screened(const float* d_tiled, const void* d_bf16, int64_t n_rows, const float* d_queries,
+                               int nq, int k, int64_t id_offset, float* d_out_scores, int64_t* d_out_ids,
+                               int* d_status, void* d_workspace, size_t workspace_bytes, void* stream,
+                               void* ev_scan_begin, void* ev_scan_end);
+
 /* One-pass variant for the online shape (reference: src/serve/app.py:285-301, schemas.py:12-16 -
  * one query, k <= 100, rerank_top_k <= 200).  sskd_index_search serves k > SSKD_K_PASS by chained
  * corpus passes; this entry point scans the corpus ONCE with plain per-lane lists, collects the best

@@ -129,7 +129,16 @@ struct ScanParams {
   int n_slices;
   int tiles_per_slice;
   int lists_per_query;
+  const int* nq_dev;       // optional: the number of queries actually present (<= nq) lives on the device
 };
+
+// number of queries to serve: the host bound, or the device-side count when one is given (the
+// screened search sizes its exact fallback launch for a cap and lets the device say how many exist)
+__device__ inline int eff_nq(int nq_host, const int* nq_dev) {
+  if (!nq_dev) return nq_host;
+  const int n = *nq_dev;
+  return n < nq_host ? n : nq_host;
+}
 
 // strict "a ranks before b": higher score first, then lower id
 __device__ inline bool ranks_before(float sa, int ia, float sb, int ib) {
@@ -265,13 +274,15 @@ __global__ __launch_bounds__(WAVES * 64) void scan_topk_kernel(ScanParams p) {
   const int slice = blockIdx.x % p.n_slices;  // blocks b, b+8 share an XCD: a slice stays on one L2
   const int qblk = blockIdx.x / p.n_slices;
   const int q0 = qblk * (32 * QB);
+  const int nq = eff_nq(p.nq, p.nq_dev);
+  if (q0 >= nq) return;  // (workgroup-uniform)
 
   // stage the query block in B-operand order (zero rows past nq)
   for (int idx = tid; idx < QB * 32 * CHUNKS; idx += WAVES * 64) {
     const int c = idx % CHUNKS, jj = idx / CHUNKS;
     const int q = q0 + jj;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (q < p.nq) v = reinterpret_cast<const float4*>(p.queries)[(int64_t)q * CHUNKS + c];
+    if (q < nq) v = reinterpret_cast<const float4*>(p.queries)[(int64_t)q * CHUNKS + c];
     qs[((jj >> 5) * CHUNKS + c) * 32 + (jj & 31)] = v;
   }
   __syncthreads();
@@ -293,14 +304,14 @@ __global__ __launch_bounds__(WAVES * 64) void scan_topk_kernel(ScanParams p) {
   for (int qq = 0; qq < QB; ++qq) {
     gthr[qq] = -INFINITY;
     const int qg = q0 + qq * 32 + j;
-    real[qq] = qg < p.nq;
-    tau_q[qq] = p.tau + (real[qq] ? qg : p.nq - 1);
+    real[qq] = qg < nq;
+    tau_q[qq] = p.tau + (real[qq] ? qg : nq - 1);
     list[qq].clear();
     ub_s[qq] = INFINITY;
     ub_i[qq] = -1;
     if (HAS_UB) {
       const int q = q0 + qq * 32 + j;
-      if (q < p.nq) { ub_s[qq] = p.ub_scores[q]; ub_i[qq] = p.ub_ids[q]; }
+      if (q < nq) { ub_s[qq] = p.ub_scores[q]; ub_i[qq] = p.ub_ids[q]; }
     }
   }
 
@@ -410,7 +421,7 @@ __global__ __launch_bounds__(WAVES * 64) void scan_topk_kernel(ScanParams p) {
 #pragma unroll
   for (int qq = 0; qq < QB; ++qq) {
     const int q = q0 + qq * 32 + j;
-    if (q < p.nq) {
+    if (q < nq) {
       const int64_t base =
           ((int64_t)q * p.lists_per_query + (slice * WAVES + wave) * 2 + h) * K;
 #pragma unroll
@@ -444,13 +455,14 @@ struct MergeParams {
   int64_t id_offset;
   float* ub_scores;     // optional: last selected (score, local id) per query
   int* ub_ids;
+  const int* nq_dev;    // optional device-side query count (see eff_nq)
 };
 
 template <typename IdT>
 __global__ __launch_bounds__(256) void merge_topk_kernel(MergeParams<IdT> p) {
   const int lane = threadIdx.x & 63;
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (q >= p.nq) return;
+  if (q >= eff_nq(p.nq, p.nq_dev)) return;
   const float* sc = p.scores + (int64_t)q * p.q_stride;
   const IdT* id = p.ids + (int64_t)q * p.q_stride;
 
@@ -530,6 +542,7 @@ struct ReduceParams {
   int lpg;              // lists per group, lpg * k <= REDUCE_MAX_CAND
   int groups;
   int nq;
+  const int* nq_dev;    // optional device-side query count (see eff_nq)
   float* out_scores;    // [nq][groups][k_out]
   int* out_ids;
 };
@@ -537,7 +550,7 @@ struct ReduceParams {
 __global__ __launch_bounds__(256) void reduce_lists_kernel(ReduceParams p) {
   const int lane = threadIdx.x & 63;
   const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (w >= (int64_t)p.nq * p.groups) return;
+  if (w >= (int64_t)eff_nq(p.nq, p.nq_dev) * p.groups) return;
   const int q = (int)(w / p.groups), g = (int)(w - (int64_t)q * p.groups);
   const int first = g * p.lpg;
   const int n_lists = min(p.lpg, p.lists_in - first);
@@ -703,6 +716,423 @@ __global__ __launch_bounds__(64) void similarity_kernel(const float* __restrict_
   }
 }
 
+
+// ------------------------------------------------------------------------- //
+// Screened search: bf16-MFMA screening pass + exact fp32 rescoring of the few candidates.
+//
+// The exact scan above is bound by the fp32 matrix pipe (~0.9 of its peak).  bf16 MFMAs run 16x
+// faster, so a SCREENING pass computes every score from bf16-rounded rows and queries first.
+// With e = (2^-8 (1 + 2^-9) + fp32 accumulation slack) |q| max|c| as a PROVED bound on
+// |screen score - exact fp32 score| (Cauchy-Schwarz on the two rounding errors), every row of the
+// exact top k has a screen score >= (k-th best screen score) - 2e: those rows are the candidates.
+// They are re-scored with the exact k-ordered fma chain of the fp32 MFMA, so the final scores and
+// ids are bit-identical to the exact scan's.  The per-lane lists can truncate the candidate set
+// only where a list is FULL with its last entry still inside the candidate band; that is detected
+// per query, and such queries (duplicate-heavy neighbourhoods) are answered by the exact scan in
+// a fallback launch sized for SCREEN_FALLBACK_CAP queries - results are never approximate.
+// ------------------------------------------------------------------------- //
+typedef __bf16 sbf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BSTEPS = DIM / 16;                 // 24 k-steps of the 32x32x16 bf16 MFMA
+constexpr int BTILE_VEC = BSTEPS * 64;           // 16-byte vectors per 32-row bf16 tile (24 KiB)
+constexpr int BGROUP = 8;                        // k-steps per prefetch group
+constexpr int BGROUPS = BSTEPS / BGROUP;         // 3
+constexpr float SCREEN_EPS_REL = 0.0041f;        // >= 2^-8 (1 + 2^-9) + 3 x 384 x 2^-24, see above
+constexpr int SCREEN_FALLBACK_CAP = 1024;        // queries the exact fallback launch is sized for
+constexpr int SCREEN_MAX_CAND = 256;             // candidates re-scored per query (one per thread)
+constexpr int SCREEN_MAX_ENTRIES = 4096;         // list entries of one query staged in LDS
+
+// fp32 tiled corpus -> bf16 tiled corpus in A-operand order of v_mfma_f32_32x32x16_bf16:
+// tile t, step s, lane l holds row 32t + (l & 31), columns 16s + 8(l >> 5) + 0..7
+__global__ __launch_bounds__(256) void make_bf16_tiles_kernel(const float4* __restrict__ tiled, int64_t n_tiles,
+                                                              sbf16x8* __restrict__ out, int* __restrict__ max_norm2) {
+  __shared__ float rowss[32];
+  const int64_t t = blockIdx.x;
+  if (threadIdx.x < 32) rowss[threadIdx.x] = 0.f;
+  __syncthreads();
+  const float4* src = tiled + t * (int64_t)(TILE_ROWS * CHUNKS);
+  for (int v = threadIdx.x; v < BTILE_VEC; v += 256) {
+    const int sidx = v >> 6, l = v & 63, r = l & 31, hh = l >> 5;
+    const int u = 2 * sidx + hh;
+    const float4 a = src[u * 64 + r], b = src[u * 64 + r + 32];
+    sbf16x8 o;
+    o[0] = (__bf16)a.x; o[1] = (__bf16)a.y; o[2] = (__bf16)a.z; o[3] = (__bf16)a.w;
+    o[4] = (__bf16)b.x; o[5] = (__bf16)b.y; o[6] = (__bf16)b.z; o[7] = (__bf16)b.w;
+    out[t * BTILE_VEC + v] = o;
+    atomicAdd(&rowss[r], a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w);
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) atomicMax(max_norm2, __float_as_int(rowss[threadIdx.x]));  // non-negative floats order as ints
+}
+
+// per query: 2e = 2 SCREEN_EPS_REL |q| max|c|
+__global__ __launch_bounds__(256) void screen_eps_kernel(const float* __restrict__ queries, int nq,
+                                                         const int* __restrict__ max_norm2, float* __restrict__ eps2) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= nq) return;
+  float ss = 0.f;
+  for (int i = lane; i < DIM; i += 64) ss += queries[(int64_t)q * DIM + i] * queries[(int64_t)q * DIM + i];
+  ss = wave_sum(ss);
+  // round the bound UP a little: sqrt / multiply roundings must not shrink it
+  if (lane == 0) eps2[q] = 2.0f * SCREEN_EPS_REL * sqrtf(ss) * sqrtf(__int_as_float(*max_norm2)) * 1.0001f + 1e-30f;
+}
+
+struct ScreenParams {
+  const sbf16x8* tiled;     // bf16 tiles
+  const float* queries;     // fp32 [nq][384] (rounded to bf16 while staging)
+  const float* eps2;        // [nq]
+  float* part_scores;       // [nq][lists_per_query][K] screen scores
+  int* part_ids;
+  int* tau;
+  int* gpool;
+  int64_t n_rows;
+  int n_tiles;
+  int nq;
+  int n_slices;
+  int tiles_per_slice;
+  int lists_per_query;
+};
+
+__device__ inline void load_bgroup(sbf16x8 (&buf)[BGROUP], const sbf16x8* __restrict__ base) {
+#pragma unroll
+  for (int s = 0; s < BGROUP; ++s) buf[s] = base[s * 64];
+}
+
+template <int QB, int G>
+__device__ inline void compute_bgroup(const sbf16x8 (&a)[BGROUP], const sbf16x8* __restrict__ qlane, f32x16 (&acc)[QB]) {
+  asm volatile("" ::: "memory");  // keep the LDS query reads inside the group (see compute_group)
+#pragma unroll
+  for (int s = 0; s < BGROUP; ++s) {
+#pragma unroll
+    for (int qq = 0; qq < QB; ++qq) {
+      const sbf16x8 b = qlane[(qq * BSTEPS + G * BGROUP + s) * 64];
+      acc[qq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b, acc[qq], 0, 0, 0);
+    }
+  }
+}
+
+// Same structure as scan_topk_kernel (query block in LDS, per-lane sorted lists, shared pruning
+// pools) on bf16 operands; the pools prune 2e BELOW the shared bound so that the whole candidate
+// band survives.
+template <int K, int QB, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void screen_topk_kernel(ScreenParams p) {
+  extern __shared__ float4 qs_raw[];
+  sbf16x8* const qs = reinterpret_cast<sbf16x8*>(qs_raw);  // [QB][24 steps][64 lanes]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int slice = blockIdx.x % p.n_slices;
+  const int qblk = blockIdx.x / p.n_slices;
+  const int q0 = qblk * (32 * QB);
+
+  for (int idx = tid; idx < QB * BSTEPS * 64; idx += WAVES * 64) {
+    const int l = idx & 63, sidx = (idx >> 6) % BSTEPS, qq = idx / (64 * BSTEPS);
+    const int q = q0 + qq * 32 + (l & 31);
+    sbf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+    if (q < p.nq) {
+      const float4* src = reinterpret_cast<const float4*>(p.queries + (int64_t)q * DIM + 16 * sidx + 8 * (l >> 5));
+      const float4 a = src[0], b = src[1];
+      v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
+      v[4] = (__bf16)b.x; v[5] = (__bf16)b.y; v[6] = (__bf16)b.z; v[7] = (__bf16)b.w;
+    }
+    qs[idx] = v;
+  }
+  int* const pool = reinterpret_cast<int*>(qs + QB * BSTEPS * 64);
+  int* const wthr = pool + QB * 32 * K;
+  for (int i = tid; i < QB * 32 * (K + 1); i += WAVES * 64) pool[i] = (int)0x80000000;
+  __syncthreads();
+  const sbf16x8* qlane = qs + lane;
+
+  LaneList<K> list[QB];
+  float gthr[QB];   // best known lower bound on the query's final K-th SCREEN score, minus 2e
+  float band[QB];
+  int* tau_q[QB];
+  bool real[QB];
+#pragma unroll
+  for (int qq = 0; qq < QB; ++qq) {
+    gthr[qq] = -INFINITY;
+    const int qg = q0 + qq * 32 + j;
+    real[qq] = qg < p.nq;
+    tau_q[qq] = p.tau + (real[qq] ? qg : p.nq - 1);
+    band[qq] = p.eps2[real[qq] ? qg : p.nq - 1];
+    list[qq].clear();
+  }
+
+  const int t_begin = slice * p.tiles_per_slice;
+  const int t_end = min(t_begin + p.tiles_per_slice, p.n_tiles);
+  const sbf16x8* lane_base = p.tiled + lane;
+  const bool ragged = (p.n_rows & 31) != 0;
+
+  sbf16x8 bufA[BGROUP], bufB[BGROUP];
+  int t = t_begin + wave;
+  if (t < t_end) load_bgroup(bufA, lane_base + (int64_t)t * BTILE_VEC);
+
+  int tiles_done = 0;
+  for (; t < t_end; t += WAVES, ++tiles_done) {
+    const sbf16x8* tile = lane_base + (int64_t)t * BTILE_VEC;
+    const bool exchange = tiles_done < TAU_REFRESH_TILES ? (tiles_done & (tiles_done - 1)) == 0
+                                                         : tiles_done % TAU_REFRESH_TILES == 0;
+#pragma unroll
+    for (int qq = 0; qq < QB; ++qq) {
+      const int w = wthr[qq * 32 + j];
+      gthr[qq] = fmaxf(gthr[qq], ordered_to_float(w) - band[qq]);
+      if (exchange && real[qq]) {
+        const int* gb = p.gpool + (int64_t)(q0 + qq * 32 + j) * K;
+        int bmin = __hip_atomic_load(&gb[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int i = 1; i < K; ++i)
+          bmin = min(bmin, __hip_atomic_load(&gb[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const int old = atomicMax(tau_q[qq], max(w, bmin));
+        gthr[qq] = fmaxf(gthr[qq], ordered_to_float(max(old, bmin)) - band[qq]);
+      }
+    }
+    f32x16 acc[QB];
+#pragma unroll
+    for (int qq = 0; qq < QB; ++qq)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[qq][r] = 0.f;
+
+    load_bgroup(bufB, tile + 1 * BGROUP * 64);
+    compute_bgroup<QB, 0>(bufA, qlane, acc);
+    load_bgroup(bufA, tile + 2 * BGROUP * 64);
+    compute_bgroup<QB, 1>(bufB, qlane, acc);
+    if (t + WAVES < t_end) load_bgroup(bufB, tile + (int64_t)WAVES * BTILE_VEC);
+    compute_bgroup<QB, 2>(bufA, qlane, acc);
+    // the next tile's first group sits in bufB: swap roles by copying (8 registers x 4)
+#pragma unroll
+    for (int s = 0; s < BGROUP; ++s) bufA[s] = bufB[s];
+
+    const int rowbase = t * TILE_ROWS + 4 * h;
+    if (ragged && t == p.n_tiles - 1) {
+#pragma unroll
+      for (int qq = 0; qq < QB; ++qq)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (rowbase + (r & 3) + 8 * (r >> 2) >= p.n_rows) acc[qq][r] = -INFINITY;
+    }
+#pragma unroll
+    for (int qq = 0; qq < QB; ++qq) {
+      float m = acc[qq][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[qq][r]);
+      if (__any(m > list[qq].s[K - 1] && m >= gthr[qq])) {
+        bool grew = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float x = acc[qq][r];
+          const int xid = rowbase + (r & 3) + 8 * (r >> 2);
+          const bool take = x > list[qq].s[K - 1] && x >= gthr[qq];
+          if (__any(take)) {
+            if (take) {
+              list[qq].insert(x, xid);
+              if (tiles_done > 0) {
+                const int xi = float_to_ordered(x);
+                if (pool_offer<K>(pool + (qq * 32 + j) * K, wthr + qq * 32 + j, xi) && real[qq])
+                  (void)__hip_atomic_fetch_max(p.gpool + (int64_t)(q0 + qq * 32 + j) * K + xid % K, xi,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+              grew = true;
+            }
+          }
+        }
+        if (grew) {
+          if (tiles_done == 0)
+            pool_offer<K>(pool + (qq * 32 + j) * K, wthr + qq * 32 + j, float_to_ordered(list[qq].s[0]));
+          gthr[qq] = fmaxf(gthr[qq], ordered_to_float(wthr[qq * 32 + j]) - band[qq]);
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int qq = 0; qq < QB; ++qq) {
+    const int q = q0 + qq * 32 + j;
+    if (q < p.nq) {
+      const int64_t base = ((int64_t)q * p.lists_per_query + (slice * WAVES + wave) * 2 + h) * K;
+#pragma unroll
+      for (int i = 0; i < K; ++i) {
+        p.part_scores[base + i] = list[qq].s[i];
+        p.part_ids[base + i] = list[qq].id[i];
+      }
+    }
+  }
+}
+
+struct ScreenFinalParams {
+  const float* part_scores;   // [nq][lists][K] screen scores (sorted lists, (-inf, -1) padded)
+  const int* part_ids;
+  const float* eps2;
+  const float* tiled;         // fp32 tiles: exact re-scoring
+  const float* queries;
+  int K, lists, k, nq;
+  int64_t id_offset;
+  float* out_scores;          // [nq][k]
+  int64_t* out_ids;
+  int* fb_count;              // [1] pre-zeroed: queries handed to the exact fallback
+  int* fb_qid;                // [SCREEN_FALLBACK_CAP]
+  float* fb_queries;          // [SCREEN_FALLBACK_CAP][384]
+  int* status;                // [1] pre-zeroed: 1 = more unproven queries than the fallback holds
+};
+
+// block-wide "best entry ranking strictly after (bs, bi)" over per-thread candidates
+__device__ inline void block_argbest(float& s, int& i, float* red_s, int* red_i) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float os = __shfl_xor(s, o);
+    const int oi = __shfl_xor(i, o);
+    if (oi >= 0 && (i < 0 || ranks_before(os, oi, s, i))) { s = os; i = oi; }
+  }
+  if (lane == 0) { red_s[wave] = s; red_i[wave] = i; }
+  __syncthreads();
+  s = red_s[0];
+  i = red_i[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w)
+    if (red_i[w] >= 0 && (i < 0 || ranks_before(red_s[w], red_i[w], s, i))) { s = red_s[w]; i = red_i[w]; }
+  __syncthreads();
+}
+
+// One workgroup (256 threads) per query: k-th best screen score -> candidate band -> proof that no
+// list truncated the band -> exact re-scoring (the fp32 MFMA's k-ordered fma chain) -> exact top k.
+__global__ __launch_bounds__(256) void screen_finalize_kernel(ScreenFinalParams p) {
+  __shared__ float es[SCREEN_MAX_ENTRIES];
+  __shared__ int ei[SCREEN_MAX_ENTRIES];
+  __shared__ __attribute__((aligned(16))) float qv[DIM];
+  __shared__ float cs[SCREEN_MAX_CAND];
+  __shared__ int ci[SCREEN_MAX_CAND];
+  __shared__ float red_s[4];
+  __shared__ int red_i[4];
+  __shared__ int n_cand, unproven;
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const int L = p.lists * p.K;
+  const int64_t base = (int64_t)q * L;
+  for (int e = tid; e < L; e += 256) {
+    es[e] = p.part_scores[base + e];
+    ei[e] = p.part_ids[base + e];
+  }
+  for (int c = tid; c < DIM; c += 256) qv[c] = p.queries[(int64_t)q * DIM + c];
+  if (tid == 0) { n_cand = 0; unproven = 0; }
+  __syncthreads();
+
+  // k-th best screen entry in rank order (k rounds of bounded arg-best)
+  float bs = INFINITY;
+  int bi = -1;
+  bool have = false;
+  float kth = -INFINITY;
+  int found = 0;
+  for (int r = 0; r < p.k; ++r) {
+    float s = -INFINITY;
+    int i = -1;
+    for (int e = tid; e < L; e += 256) {
+      const int id = ei[e];
+      if (id < 0) continue;
+      const float v = es[e];
+      if (have && !ranks_before(bs, bi, v, id)) continue;
+      if (i < 0 || ranks_before(v, id, s, i)) { s = v; i = id; }
+    }
+    block_argbest(s, i, red_s, red_i);
+    if (i < 0) break;
+    bs = s; bi = i; have = true;
+    kth = s;
+    ++found;
+  }
+  // fewer than k rows exist at all: every entry is a candidate
+  const float tau = found == p.k ? kth - p.eps2[q] : -INFINITY;
+
+  // proof: a FULL list whose last entry is still inside the band may have dropped candidates
+  for (int l = tid; l < p.lists; l += 256) {
+    const int e = l * p.K + p.K - 1;
+    if (ei[e] >= 0 && es[e] >= tau) unproven = 1;
+  }
+  for (int e = tid; e < L; e += 256) {
+    if (ei[e] >= 0 && es[e] >= tau) {
+      const int slot = atomicAdd(&n_cand, 1);
+      if (slot < SCREEN_MAX_CAND) ci[slot] = ei[e];
+    }
+  }
+  __syncthreads();
+  if (n_cand > SCREEN_MAX_CAND) unproven = 1;
+  __syncthreads();
+  if (unproven) {
+    __shared__ int slot_s;
+    if (tid == 0) {
+      slot_s = atomicAdd(p.fb_count, 1);
+      if (slot_s < SCREEN_FALLBACK_CAP) p.fb_qid[slot_s] = q;
+      else atomicMax(p.status, 1);
+    }
+    __syncthreads();
+    const int slot = slot_s;
+    if (slot < SCREEN_FALLBACK_CAP) {
+      for (int c = tid; c < DIM; c += 256) p.fb_queries[(int64_t)slot * DIM + c] = qv[c];
+    } else {
+      for (int r = tid; r < p.k; r += 256) {  // loud, never plausible
+        p.out_scores[(int64_t)q * p.k + r] = __int_as_float(0x7fc00000);
+        p.out_ids[(int64_t)q * p.k + r] = -2;
+      }
+    }
+    return;
+  }
+
+  // exact score of candidate `tid`: the fma order of the 32x32x2 f32 MFMA chain
+  const int M = n_cand;
+  float my_s = -INFINITY;
+  int my_i = -1;
+  if (tid < M) {
+    const int row = ci[tid];
+    const float4* src = reinterpret_cast<const float4*>(p.tiled) + (int64_t)(row >> 5) * (TILE_ROWS * CHUNKS) + (row & 31);
+    float acc = 0.f;
+#pragma unroll 4
+    for (int u = 0; u < STEPS; ++u) {
+      const float4 a = src[u * 64], b = src[u * 64 + 32];
+      const float4 qa = *reinterpret_cast<const float4*>(&qv[8 * u]), qb = *reinterpret_cast<const float4*>(&qv[8 * u + 4]);
+      acc = fmaf(a.x, qa.x, acc); acc = fmaf(b.x, qb.x, acc);
+      acc = fmaf(a.y, qa.y, acc); acc = fmaf(b.y, qb.y, acc);
+      acc = fmaf(a.z, qa.z, acc); acc = fmaf(b.z, qb.z, acc);
+      acc = fmaf(a.w, qa.w, acc); acc = fmaf(b.w, qb.w, acc);
+    }
+    my_s = acc;
+    my_i = row;
+    if (!(acc == acc)) my_i = -1;  // a NaN score is never selected (as in the exact scan)
+  }
+  bs = INFINITY; bi = -1; have = false;
+  for (int r = 0; r < p.k; ++r) {
+    float s = my_s;
+    int i = my_i;
+    if (i >= 0 && have && !ranks_before(bs, bi, s, i)) i = -1;
+    block_argbest(s, i, red_s, red_i);
+    if (tid == 0) {
+      p.out_scores[(int64_t)q * p.k + r] = i >= 0 ? s : -FLT_MAX;
+      p.out_ids[(int64_t)q * p.k + r] = i >= 0 ? (int64_t)i + p.id_offset : -1;
+    }
+    if (i < 0) {
+      for (int rr = r + 1 + tid; rr < p.k; rr += 256) {
+        p.out_scores[(int64_t)q * p.k + rr] = -FLT_MAX;
+        p.out_ids[(int64_t)q * p.k + rr] = -1;
+      }
+      break;
+    }
+    bs = s; bi = i; have = true;
+  }
+}
+
+__global__ __launch_bounds__(256) void screen_scatter_kernel(const int* __restrict__ fb_count, const int* __restrict__ fb_qid,
+                                                             const float* __restrict__ fb_scores,
+                                                             const int64_t* __restrict__ fb_ids, int k,
+                                                             float* __restrict__ out_scores, int64_t* __restrict__ out_ids) {
+  const int n = min(*fb_count, SCREEN_FALLBACK_CAP);
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    const int q = fb_qid[i];
+    for (int r = threadIdx.x; r < k; r += 256) {
+      out_scores[(int64_t)q * k + r] = fb_scores[(int64_t)i * k + r];
+      out_ids[(int64_t)q * k + r] = fb_ids[(int64_t)i * k + r];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------- //
 // launch plan
 // ------------------------------------------------------------------------- //
@@ -801,6 +1231,12 @@ int dispatch_scan(const Plan& pl, const ScanParams& sp, hipStream_t st) {
 // ------------------------------------------------------------------------- //
 // C-ABI
 // ------------------------------------------------------------------------- //
+
+static int exact_search_impl(const float* d_tiled, int64_t n_rows, const float* d_queries, int nq,
+                             int k, int64_t id_offset, float* d_out_scores, int64_t* d_out_ids,
+                             void* d_workspace, size_t workspace_bytes, void* stream,
+                             const sskd_search_tuning* tuning, void* ev_scan_begin, void* ev_scan_end,
+                             const int* nq_dev);
 
 extern "C" {
 
@@ -904,6 +1340,18 @@ int sskd_index_search_ex(const float* d_tiled, int64_t n_rows, const float* d_qu
                          int k, int64_t id_offset, float* d_out_scores, int64_t* d_out_ids,
                          void* d_workspace, size_t workspace_bytes, void* stream,
                          const sskd_search_tuning* tuning, void* ev_scan_begin, void* ev_scan_end) {
+  return exact_search_impl(d_tiled, n_rows, d_queries, nq, k, id_offset, d_out_scores, d_out_ids, d_workspace,
+                           workspace_bytes, stream, tuning, ev_scan_begin, ev_scan_end, nullptr);
+}
+
+}  // extern "C"
+
+// the exact search proper; nq_dev (optional) = device-side count of the queries present (<= nq)
+static int exact_search_impl(const float* d_tiled, int64_t n_rows, const float* d_queries, int nq,
+                             int k, int64_t id_offset, float* d_out_scores, int64_t* d_out_ids,
+                             void* d_workspace, size_t workspace_bytes, void* stream,
+                             const sskd_search_tuning* tuning, void* ev_scan_begin, void* ev_scan_end,
+                             const int* nq_dev) {
   SSKD_REQUIRE(n_rows >= 0, "index_search: n_rows < 0");
   SSKD_REQUIRE(nq >= 0, "index_search: nq < 0");
   SSKD_REQUIRE(k >= 1 && k <= SSKD_K_MAX, "index_search: k=%d outside [1, %d]", k, SSKD_K_MAX);
@@ -958,6 +1406,7 @@ int sskd_index_search_ex(const float* d_tiled, int64_t n_rows, const float* d_qu
   sp.n_slices = pl.n_slices;
   sp.tiles_per_slice = pl.tiles_per_slice;
   sp.lists_per_query = pl.lists_per_query;
+  sp.nq_dev = nq_dev;
 
   for (int pass = 0; pass < pl.passes; ++pass) {
     hipLaunchKernelGGL(fill_int_kernel, dim3((unsigned)sskd::ceil_div(nq * (1 + pl.K), 256)), dim3(256),
@@ -979,6 +1428,7 @@ int sskd_index_search_ex(const float* d_tiled, int64_t n_rows, const float* d_qu
       rp.lpg = pl.reduce_lpg;
       rp.groups = (int)sskd::ceil_div(lists, pl.reduce_lpg);
       rp.nq = nq;
+      rp.nq_dev = nq_dev;
       rp.out_scores = red_scores[step & 1];
       rp.out_ids = red_ids[step & 1];
       hipLaunchKernelGGL(reduce_lists_kernel, dim3((unsigned)sskd::ceil_div((int64_t)nq * rp.groups, 4)),
@@ -990,6 +1440,7 @@ int sskd_index_search_ex(const float* d_tiled, int64_t n_rows, const float* d_qu
       lists = rp.groups;
     }
     MergeParams<int> mp{};
+    mp.nq_dev = nq_dev;
     mp.scores = cand_scores;
     mp.ids = cand_ids;
     mp.list_stride = pl.K;
@@ -1013,6 +1464,8 @@ int sskd_index_search_ex(const float* d_tiled, int64_t n_rows, const float* d_qu
   }
   return SSKD_OK;
 }
+
+extern "C" {
 
 namespace {
 constexpr int ONEPASS_MAX_NQ = 64, ONEPASS_MAX_K = 256;
@@ -1216,6 +1669,188 @@ int sskd_similarity(const float* d_q, int nq, const float* d_d, int nd, int dim,
                      dim3((unsigned)sskd::ceil_div(nd, 32), (unsigned)sskd::ceil_div(nq, 32)),
                      dim3(64), 0, sskd::as_stream(stream), d_q, nq, d_d, nd, dim, d_out);
   return sskd::check_launch("similarity_kernel");
+}
+
+
+// ---- screened search (bf16 screening + exact re-scoring): see the kernels above -----------------
+
+namespace {
+struct ScreenPlan {
+  int QB, n_qblocks, n_slices, tiles_per_slice, n_tiles, lists_per_query;
+  size_t part_elems;
+};
+
+bool screen_plan(int64_t n_rows, int nq, int k, ScreenPlan* sp) {
+  if (k < 1 || k > 10 || nq < 64 || n_rows < 64 * TILE_ROWS) return false;
+  ScreenPlan pl{};
+  pl.n_tiles = (int)sskd::ceil_div(n_rows, TILE_ROWS);
+  pl.QB = nq >= 256 ? 4 : 2;
+  pl.n_qblocks = (int)sskd::ceil_div(nq, 32 * pl.QB);
+  int slices = (int)sskd::ceil_div(1024, pl.n_qblocks);
+  slices = (int)sskd::ceil_div(slices, 8) * 8;
+  const int max_by_lists = SCREEN_MAX_ENTRIES / (10 * 16);       // lists = slices * 8 waves * 2
+  if (slices > max_by_lists) slices = max_by_lists / 8 * 8;
+  const int max_slices = (int)sskd::ceil_div(pl.n_tiles, 8);
+  if (slices > max_slices) slices = max_slices;
+  if (slices < 1) slices = 1;
+  pl.tiles_per_slice = (int)sskd::ceil_div(pl.n_tiles, slices);
+  pl.n_slices = (int)sskd::ceil_div(pl.n_tiles, pl.tiles_per_slice);
+  pl.lists_per_query = pl.n_slices * 8 * 2;
+  if (pl.lists_per_query * 10 > SCREEN_MAX_ENTRIES) return false;
+  pl.part_elems = (size_t)nq * pl.lists_per_query * 10;
+  *sp = pl;
+  return true;
+}
+
+struct ScreenWs {
+  float* part_scores;
+  int* part_ids;
+  int* tau;          // [nq] + gpool [nq * 10]
+  float* eps2;
+  int* fb_count;     // [2]: count, spare
+  int* fb_qid;
+  float* fb_queries;
+  float* fb_scores;
+  int64_t* fb_ids;
+  void* exact_ws;
+  size_t exact_bytes;
+  size_t bytes;
+};
+
+ScreenWs screen_carve(void* base, const ScreenPlan& pl, int64_t n_rows, int nq, int k) {
+  char* p = static_cast<char*>(base);
+  auto take = [&](size_t bytes) {
+    char* r = p;
+    p += align256(bytes);
+    return static_cast<void*>(r);
+  };
+  ScreenWs w{};
+  w.part_scores = static_cast<float*>(take(pl.part_elems * sizeof(float)));
+  w.part_ids = static_cast<int*>(take(pl.part_elems * sizeof(int)));
+  w.tau = static_cast<int*>(take((size_t)nq * 11 * sizeof(int)));
+  w.eps2 = static_cast<float*>(take((size_t)nq * sizeof(float)));
+  w.fb_count = static_cast<int*>(take(256));
+  w.fb_qid = static_cast<int*>(take(SCREEN_FALLBACK_CAP * sizeof(int)));
+  w.fb_queries = static_cast<float*>(take((size_t)SCREEN_FALLBACK_CAP * DIM * sizeof(float)));
+  w.fb_scores = static_cast<float*>(take((size_t)SCREEN_FALLBACK_CAP * k * sizeof(float)));
+  w.fb_ids = static_cast<int64_t*>(take((size_t)SCREEN_FALLBACK_CAP * k * sizeof(int64_t)));
+  w.exact_bytes = sskd_index_search_workspace_bytes(n_rows, SCREEN_FALLBACK_CAP, k);
+  w.exact_ws = take(w.exact_bytes);
+  w.bytes = (size_t)(p - static_cast<char*>(base));
+  return w;
+}
+}  // namespace
+
+size_t sskd_index_bf16_bytes(int64_t n_rows) {
+  if (n_rows <= 0) return 0;
+  return (size_t)sskd_index_padded_rows(n_rows) * DIM * 2 + 256;  // tiles + { max |row|^2 }
+}
+
+int sskd_index_make_bf16(const float* d_tiled, int64_t n_rows, void* d_bf16, void* stream) {
+  SSKD_REQUIRE(n_rows >= 0, "index_make_bf16: n_rows < 0");
+  if (n_rows == 0) return SSKD_OK;
+  SSKD_REQUIRE(d_tiled && d_bf16, "index_make_bf16: null pointer");
+  hipStream_t st = sskd::as_stream(stream);
+  const int64_t tiles = sskd::ceil_div(n_rows, TILE_ROWS);
+  int* max_norm2 = reinterpret_cast<int*>(static_cast<char*>(d_bf16) + (size_t)tiles * BTILE_VEC * 16);
+  if (hipMemsetAsync(max_norm2, 0, 256, st) != hipSuccess) return sskd::fail(SSKD_ERR_HIP, "index_make_bf16: memset failed");
+  hipLaunchKernelGGL(make_bf16_tiles_kernel, dim3((unsigned)tiles), dim3(256), 0, st,
+                     reinterpret_cast<const float4*>(d_tiled), tiles, static_cast<sbf16x8*>(d_bf16), max_norm2);
+  return sskd::check_launch("make_bf16_tiles_kernel");
+}
+
+size_t sskd_index_search_screened_workspace_bytes(int64_t n_rows, int nq, int k) {
+  ScreenPlan pl{};
+  if (!screen_plan(n_rows, nq, k, &pl)) return 0;
+  return screen_carve(nullptr, pl, n_rows, nq, k).bytes;
+}
+
+int sskd_index_search_screened(const float* d_tiled, const void* d_bf16, int64_t n_rows, const float* d_queries,
+                               int nq, int k, int64_t id_offset, float* d_out_scores, int64_t* d_out_ids,
+                               int* d_status, void* d_workspace, size_t workspace_bytes, void* stream,
+                               void* ev_scan_begin, void* ev_scan_end) {
+  ScreenPlan pl{};
+  if (!screen_plan(n_rows, nq, k, &pl))
+    return sskd::fail(SSKD_ERR_UNSUPPORTED,
+                      "index_search_screened: needs k <= 10, nq >= 64 and >= 2048 rows (got k=%d nq=%d rows=%lld): "
+                      "use sskd_index_search", k, nq, (long long)n_rows);
+  SSKD_REQUIRE(n_rows < ((int64_t)1 << 31) - 64, "index_search_screened: shard too large for int32 row ids");
+  SSKD_REQUIRE(d_tiled && d_bf16 && d_queries && d_out_scores && d_out_ids && d_status,
+               "index_search_screened: null pointer");
+  const size_t need = sskd_index_search_screened_workspace_bytes(n_rows, nq, k);
+  if (!d_workspace || workspace_bytes < need)
+    return sskd::fail(SSKD_ERR_WORKSPACE, "index_search_screened: workspace %zu B < required %zu B", workspace_bytes, need);
+  hipStream_t st = sskd::as_stream(stream);
+  const ScreenWs w = screen_carve(d_workspace, pl, n_rows, nq, k);
+  const int64_t tiles = sskd::ceil_div(n_rows, TILE_ROWS);
+  const int* max_norm2 = reinterpret_cast<const int*>(static_cast<const char*>(d_bf16) + (size_t)tiles * BTILE_VEC * 16);
+
+  hipLaunchKernelGGL(fill_int_kernel, dim3((unsigned)sskd::ceil_div(nq * 11, 256)), dim3(256), 0, st, w.tau, nq * 11,
+                     (int)0x80000000);
+  if (hipMemsetAsync(w.fb_count, 0, 256, st) != hipSuccess || hipMemsetAsync(d_status, 0, 2 * sizeof(int), st) != hipSuccess)
+    return sskd::fail(SSKD_ERR_HIP, "index_search_screened: memset failed");
+  hipLaunchKernelGGL(screen_eps_kernel, dim3((unsigned)sskd::ceil_div(nq, 4)), dim3(256), 0, st, d_queries, nq, max_norm2, w.eps2);
+
+  ScreenParams sp{};
+  sp.tiled = static_cast<const sbf16x8*>(d_bf16);
+  sp.queries = d_queries;
+  sp.eps2 = w.eps2;
+  sp.part_scores = w.part_scores;
+  sp.part_ids = w.part_ids;
+  sp.tau = w.tau;
+  sp.gpool = w.tau + nq;
+  sp.n_rows = n_rows;
+  sp.n_tiles = pl.n_tiles;
+  sp.nq = nq;
+  sp.n_slices = pl.n_slices;
+  sp.tiles_per_slice = pl.tiles_per_slice;
+  sp.lists_per_query = pl.lists_per_query;
+  const size_t lds = (size_t)pl.QB * BSTEPS * 64 * 16 + (size_t)pl.QB * 32 * 11 * sizeof(int);
+  if (ev_scan_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_scan_begin), st);
+  if (pl.QB == 4) {
+    auto kern = screen_topk_kernel<10, 4, 8>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(pl.n_qblocks * pl.n_slices), dim3(512), lds, st, sp);
+  } else {
+    auto kern = screen_topk_kernel<10, 2, 8>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(pl.n_qblocks * pl.n_slices), dim3(512), lds, st, sp);
+  }
+  if (ev_scan_end) (void)hipEventRecord(static_cast<hipEvent_t>(ev_scan_end), st);
+  int rc = sskd::check_launch("screen_topk_kernel");
+  if (rc != SSKD_OK) return rc;
+
+  ScreenFinalParams fp{};
+  fp.part_scores = w.part_scores;
+  fp.part_ids = w.part_ids;
+  fp.eps2 = w.eps2;
+  fp.tiled = d_tiled;
+  fp.queries = d_queries;
+  fp.K = 10;
+  fp.lists = pl.lists_per_query;
+  fp.k = k;
+  fp.nq = nq;
+  fp.id_offset = id_offset;
+  fp.out_scores = d_out_scores;
+  fp.out_ids = d_out_ids;
+  fp.fb_count = w.fb_count;
+  fp.fb_qid = w.fb_qid;
+  fp.fb_queries = w.fb_queries;
+  fp.status = d_status;
+  hipLaunchKernelGGL(screen_finalize_kernel, dim3(nq), dim3(256), 0, st, fp);
+  if ((rc = sskd::check_launch("screen_finalize_kernel")) != SSKD_OK) return rc;
+
+  // exact scan for the queries whose candidate band could not be proven complete (usually none:
+  // every workgroup of these launches then exits on its first instruction)
+  rc = exact_search_impl(d_tiled, n_rows, w.fb_queries, SCREEN_FALLBACK_CAP, k, id_offset, w.fb_scores, w.fb_ids,
+                         w.exact_ws, w.exact_bytes, stream, nullptr, nullptr, nullptr, w.fb_count);
+  if (rc != SSKD_OK) return rc;
+  hipLaunchKernelGGL(screen_scatter_kernel, dim3(64), dim3(256), 0, st, w.fb_count, w.fb_qid, w.fb_scores, w.fb_ids, k,
+                     d_out_scores, d_out_ids);
+  if ((rc = sskd::check_launch("screen_scatter_kernel")) != SSKD_OK) return rc;
+  if (hipMemcpyAsync(d_status + 1, w.fb_count, sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return sskd::fail(SSKD_ERR_HIP, "index_search_screened: status copy failed");
+  return SSKD_OK;
 }
 
 }  // extern "C"

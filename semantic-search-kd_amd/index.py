@@ -86,6 +86,13 @@ class FAISSIndexBuilder:
         # explicit launch tuning (``_native.SearchTuning``) handed to BOTH the workspace query and the
         # search call; ``None`` = the built-in plan.  There is no environment knob behind the search.
         self.search_tuning: Optional[_native.SearchTuning] = None
+        # batch searches (k <= 10, >= 64 queries) go through the bf16-screened path: identical bits to
+        # the exact scan (proved error band + exact re-scoring + exact fallback), several times faster.
+        # ``screening = False`` forces the plain exact scan.
+        self.screening = True
+        self._bf16: Optional[torch.Tensor] = None      # bf16 copy of the tiles (+ max row norm), made lazily
+        self._bf16_rows = -1
+        self.last_status: Optional[torch.Tensor] = None  # device int32[2] of the last screened search
         self.index: Optional[IndexHandle] = None
 
     # ------------------------------------------------------------------ storage
@@ -156,6 +163,7 @@ class FAISSIndexBuilder:
                 )
             )
         self._n += n_new
+        self._bf16_rows = -1  # the bf16 screening copy is stale
         self.index = IndexHandle(self)
 
     def build_from_embeddings(
@@ -249,6 +257,25 @@ class FAISSIndexBuilder:
         if nq == 0:
             return out_scores, out_ids
         tuning = self.search_tuning
+        if self.screening and tuning is None and self._tiled is not None:
+            need = int(lib.sskd_index_search_screened_workspace_bytes(self._n, nq, k))
+            if need:
+                if self._bf16 is None or self._bf16_rows != self._n:
+                    self._bf16 = torch.empty(int(lib.sskd_index_bf16_bytes(self._n)), dtype=torch.uint8, device=self.device)
+                    _native.check(lib.sskd_index_make_bf16(self._tiled.data_ptr(), self._n, self._bf16.data_ptr(), stream))
+                    self._bf16_rows = self._n
+                if self._workspace is None or self._workspace.numel() < need:
+                    self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+                self.last_status = torch.empty(2, dtype=torch.int32, device=self.device)
+                _native.check(
+                    lib.sskd_index_search_screened(
+                        self._tiled.data_ptr(), self._bf16.data_ptr(), self._n, q.data_ptr(), nq, k, self.id_offset,
+                        out_scores.data_ptr(), out_ids.data_ptr(), self.last_status.data_ptr(),
+                        self._workspace.data_ptr(), self._workspace.numel(), stream, None, None,
+                    )
+                )
+                return out_scores, out_ids
+        self.last_status = None
         need = int(lib.sskd_index_search_workspace_bytes_ex(self._n, nq, k, tuning))
         if self._workspace is None or self._workspace.numel() < need:
             self._workspace = torch.empty(max(need, 1), dtype=torch.uint8, device=self.device)
@@ -325,6 +352,14 @@ class FAISSIndexBuilder:
             else:
                 self.last_search_path = "chained" if k > _native.SSKD_K_PASS else "single"
             scores, ids = self.search_device(qd, k, normalize_queries=normalize_queries)
+            if self.last_status is not None and int(self.last_status[0].item()) != 0:
+                # more unproven queries than the screened call's exact fallback holds: plain exact scan
+                self.screening, keep = False, self.screening
+                try:
+                    scores, ids = self.search_device(qd, k, normalize_queries=normalize_queries)
+                finally:
+                    self.screening = keep
+                self.last_search_path += "+exact-rerun"
             return scores.cpu().numpy(), ids.cpu().numpy()
 
     def search(self, query_emb: np.ndarray, k: int = 10) -> Tuple[np.ndarray, np.ndarray]:

@@ -1,0 +1,124 @@
+"""Screened search (bf16-MFMA screening + exact re-scoring): bit-identical to the exact scan.
+
+Every case demands the same bits as ``oracle.search.topk_fma`` (the exact path's oracle), i.e. the
+same gate as tests/test_search_gpu.py; on top, the fallback machinery is forced: duplicate-heavy
+corpora (a per-lane list full inside the candidate band -> exact fallback inside the call) and more
+unproven queries than the fallback holds (status flag -> the host path re-runs the exact scan).
+"""
+import numpy as np
+import pytest
+import torch
+
+from capi_helpers import stream, tile_corpus
+from oracle import search as oracle
+from semantic_search_kd_amd import FAISSIndexBuilder, _native
+
+pytestmark = pytest.mark.gpu
+
+
+def screened(lib, corpus, queries, k, id_offset=0):
+    n, nq = corpus.shape[0], queries.shape[0]
+    tiled = tile_corpus(lib, corpus)
+    bf = torch.empty(int(lib.sskd_index_bf16_bytes(n)), dtype=torch.uint8, device="cuda")
+    _native.check(lib.sskd_index_make_bf16(tiled.data_ptr(), n, bf.data_ptr(), stream()))
+    q = torch.from_numpy(np.ascontiguousarray(queries, np.float32)).cuda()
+    out_s = torch.full((nq, k), float("nan"), device="cuda")
+    out_i = torch.full((nq, k), -7, dtype=torch.int64, device="cuda")
+    status = torch.full((2,), -1, dtype=torch.int32, device="cuda")
+    need = int(lib.sskd_index_search_screened_workspace_bytes(n, nq, k))
+    assert need > 0
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    _native.check(lib.sskd_index_search_screened(tiled.data_ptr(), bf.data_ptr(), n, q.data_ptr(), nq, k, id_offset,
+                                                 out_s.data_ptr(), out_i.data_ptr(), status.data_ptr(), ws.data_ptr(),
+                                                 ws.numel(), stream(), None, None))
+    torch.cuda.synchronize()
+    return out_s.cpu().numpy(), out_i.cpu().numpy(), status.cpu().numpy()
+
+
+@pytest.mark.parametrize("n,nq,k", [
+    (2048, 64, 10), (2049, 65, 10), (5000, 130, 1), (20000, 300, 10), (20011, 257, 7), (100000, 1000, 10),
+])
+def test_screened_equals_exact_bits(gpu, native_lib, n, nq, k):
+    corpus = oracle.seeded_unit_rows(n, 384, 100 + n % 97)
+    queries = oracle.seeded_unit_rows(nq, 384, 200 + nq)
+    # planted near neighbours make the top ranks non-trivial
+    for i in range(0, nq, 7):
+        queries[i] = corpus[(i * 37) % n] + 0.05 * queries[i]
+        queries[i] /= np.linalg.norm(queries[i])
+    s, i, st = screened(native_lib, corpus, queries, k, id_offset=1000)
+    ref_s, ref_i = oracle.topk_fma(queries, corpus, k, 1000)
+    assert st[0] == 0
+    assert np.array_equal(i, ref_i) and np.array_equal(s, ref_s)
+
+
+def test_screened_unnormalised_rows_and_queries(gpu, native_lib):
+    """metric = ip: the error band scales with |q| max|row|."""
+    rng = np.random.default_rng(3)
+    corpus = oracle.seeded_unit_rows(6000, 384, 5) * rng.uniform(0.1, 30.0, size=(6000, 1)).astype(np.float32)
+    queries = oracle.seeded_unit_rows(100, 384, 6) * rng.uniform(0.01, 100.0, size=(100, 1)).astype(np.float32)
+    s, i, st = screened(native_lib, corpus, queries, 10)
+    ref_s, ref_i = oracle.topk_fma(queries, corpus, 10)
+    assert st[0] == 0 and np.array_equal(i, ref_i) and np.array_equal(s, ref_s)
+
+
+def test_screened_duplicates_take_the_exact_fallback(gpu, native_lib):
+    """40 consecutive copies of one row: for the queries near it the candidate band overflows a
+    per-lane list -> those queries are answered by the exact scan inside the call; ties resolve to
+    the lower id exactly as in the exact path."""
+    corpus = oracle.seeded_unit_rows(8000, 384, 11)
+    corpus[3000:3040] = corpus[77]
+    queries = oracle.seeded_unit_rows(128, 384, 12)
+    for j in range(0, 128, 4):
+        queries[j] = corpus[77] + 0.02 * queries[j]
+        queries[j] /= np.linalg.norm(queries[j])
+    s, i, st = screened(native_lib, corpus, queries, 10)
+    ref_s, ref_i = oracle.topk_fma(queries, corpus, 10)
+    assert st[0] == 0 and st[1] >= 32          # the planted queries went through the fallback
+    assert np.array_equal(i, ref_i) and np.array_equal(s, ref_s)
+    assert ref_i[0, 0] == 77 and ref_i[0, 1] == 3000  # equal scores: lower id first
+
+
+def test_screened_overflow_is_flagged_and_host_path_reruns_exact(gpu, native_lib):
+    """More unproven queries than the in-call fallback holds: status 1, poisoned rows, and the
+    product host path (FAISSIndexBuilder.search) transparently re-runs the exact scan."""
+    corpus = oracle.seeded_unit_rows(4096, 384, 21)
+    corpus[1000:1064] = corpus[5]
+    queries = np.repeat(corpus[5][None], 1200, axis=0) + 0.01 * oracle.seeded_unit_rows(1200, 384, 22)
+    queries /= np.linalg.norm(queries, axis=1, keepdims=True)
+    queries = queries.astype(np.float32)
+    s, i, st = screened(native_lib, corpus, queries, 10)
+    assert st[0] == 1 and st[1] > 1024
+    assert (i == -2).any() and np.isnan(s[i == -2]).all()
+    ok = i[:, 0] != -2
+    ref_s, ref_i = oracle.topk_fma(queries, corpus, 10)
+    assert np.array_equal(i[ok], ref_i[ok]) and np.array_equal(s[ok], ref_s[ok])
+    index = FAISSIndexBuilder(embedding_dim=384, metric="ip", device="cuda:0")
+    index.add(corpus)
+    hs, hi = index.search(queries, 10)
+    assert np.array_equal(hi, ref_i) and np.array_equal(hs, ref_s)
+    assert index.last_search_path.endswith("+exact-rerun")
+
+
+def test_product_search_device_uses_screening_and_matches_exact(gpu, native_lib):
+    corpus = oracle.seeded_unit_rows(50000, 384, 31)
+    queries = oracle.seeded_unit_rows(500, 384, 32)
+    index = FAISSIndexBuilder(embedding_dim=384, metric="ip", device="cuda:0", id_offset=7)
+    index.add(corpus[:30000])
+    q = torch.from_numpy(queries).cuda()
+    s1, i1 = index.search_device(q, 10)
+    assert index.last_status is not None and int(index.last_status[0]) == 0
+    ref = oracle.topk_fma(queries, corpus[:30000], 10, 7)
+    assert np.array_equal(i1.cpu().numpy(), ref[1]) and np.array_equal(s1.cpu().numpy(), ref[0])
+    index.add(corpus[30000:])   # the bf16 copy is rebuilt after an add
+    s2, i2 = index.search_device(q, 10)
+    ref = oracle.topk_fma(queries, corpus, 10, 7)
+    assert np.array_equal(i2.cpu().numpy(), ref[1]) and np.array_equal(s2.cpu().numpy(), ref[0])
+    index.screening = False
+    s3, i3 = index.search_device(q, 10)
+    assert index.last_status is None
+    assert torch.equal(i3, i2) and torch.equal(s3, s2)
+    # shapes outside the screened path (k > 10, few queries) silently take the exact scan
+    index.screening = True
+    s4, i4 = index.search_device(q[:10], 20)
+    ref = oracle.topk_fma(queries[:10], corpus, 20, 7)
+    assert np.array_equal(i4.cpu().numpy(), ref[1])
