@@ -734,8 +734,24 @@ __global__ __launch_bounds__(64) void similarity_kernel(const float* __restrict_
 typedef __bf16 sbf16x8 __attribute__((ext_vector_type(8)));
 constexpr int BSTEPS = DIM / 16;                 // 24 k-steps of the 32x32x16 bf16 MFMA
 constexpr int BTILE_VEC = BSTEPS * 64;           // 16-byte vectors per 32-row bf16 tile (24 KiB)
-constexpr int BGROUP = 8;                        // k-steps per prefetch group
-constexpr int BGROUPS = BSTEPS / BGROUP;         // 3
+#ifndef SSKD_SCREEN_BGROUP
+#define SSKD_SCREEN_BGROUP 4
+#endif
+#ifndef SSKD_SCREEN_WAVES
+#define SSKD_SCREEN_WAVES 8
+#endif
+#ifndef SSKD_SCREEN_RING
+#define SSKD_SCREEN_RING 3
+#endif
+#ifndef SSKD_SCREEN_LISTK
+#define SSKD_SCREEN_LISTK 6
+#endif
+constexpr int BGROUP = SSKD_SCREEN_BGROUP;       // k-steps per prefetch group
+constexpr int BGROUPS = BSTEPS / BGROUP;
+constexpr int SCREEN_WAVES = SSKD_SCREEN_WAVES;  // waves per screening workgroup
+constexpr int SCREEN_RING = SSKD_SCREEN_RING;    // register buffers of one group each; RING - 1 groups are in flight
+constexpr int SCREEN_LISTK = SSKD_SCREEN_LISTK;  // depth of the per-lane lists (the pools keep 10 slots regardless)
+static_assert(BSTEPS % BGROUP == 0 && BGROUPS % SCREEN_RING == 0 && SCREEN_RING >= 2, "screening prefetch geometry");
 constexpr float SCREEN_EPS_REL = 0.0041f;        // >= 2^-8 (1 + 2^-9) + 3 x 384 x 2^-24, see above
 constexpr int SCREEN_FALLBACK_CAP = 1024;        // queries the exact fallback launch is sized for
 constexpr int SCREEN_MAX_CAND = 256;             // candidates re-scored per query (one per thread)
@@ -798,9 +814,12 @@ __device__ inline void load_bgroup(sbf16x8 (&buf)[BGROUP], const sbf16x8* __rest
   for (int s = 0; s < BGROUP; ++s) buf[s] = base[s * 64];
 }
 
+// One group of k-steps.  (A two-deep register pipeline of the LDS query-fragment reads, pinned with
+// sched_group_barrier, was built and measured: 9.6 ms against 8.5 ms for the compiler's own
+// "two reads, wait, MFMA" placement below - the pinned order delays the tile prefetch loads.)
 template <int QB, int G>
 __device__ inline void compute_bgroup(const sbf16x8 (&a)[BGROUP], const sbf16x8* __restrict__ qlane, f32x16 (&acc)[QB]) {
-  asm volatile("" ::: "memory");  // keep the LDS query reads inside the group (see compute_group)
+  asm volatile("" ::: "memory");  // keep the (tile-invariant) LDS query reads inside the group (see compute_group)
 #pragma unroll
   for (int s = 0; s < BGROUP; ++s) {
 #pragma unroll
@@ -811,10 +830,25 @@ __device__ inline void compute_bgroup(const sbf16x8 (&a)[BGROUP], const sbf16x8*
   }
 }
 
+// one tile's groups, compile-time unrolled over a ring of RING register buffers: group G is multiplied
+// from buffer G % RING while group G + RING - 1 (of this tile, or of the wave's next tile) loads
+template <int QB, int G>
+__device__ inline void screen_tile_groups(sbf16x8 (&buf)[SCREEN_RING][BGROUP], const sbf16x8* __restrict__ tile,
+                                          const sbf16x8* __restrict__ qlane, f32x16 (&acc)[QB], bool more,
+                                          int64_t next_tile) {
+  if constexpr (G < BGROUPS) {
+    constexpr int PG = G + SCREEN_RING - 1;  // group to prefetch now
+    if constexpr (PG < BGROUPS) load_bgroup(buf[PG % SCREEN_RING], tile + PG * BGROUP * 64);
+    else if (more) load_bgroup(buf[PG % SCREEN_RING], tile + next_tile + (PG - BGROUPS) * BGROUP * 64);
+    compute_bgroup<QB, G>(buf[G % SCREEN_RING], qlane, acc);
+    screen_tile_groups<QB, G + 1>(buf, tile, qlane, acc, more, next_tile);
+  }
+}
+
 // Same structure as scan_topk_kernel (query block in LDS, per-lane sorted lists, shared pruning
 // pools) on bf16 operands; the pools prune 2e BELOW the shared bound so that the whole candidate
 // band survives.
-template <int K, int QB, int WAVES>
+template <int K, int QB, int WAVES, int LK = SCREEN_LISTK>
 __global__ __launch_bounds__(WAVES * 64) void screen_topk_kernel(ScreenParams p) {
   extern __shared__ float4 qs_raw[];
   sbf16x8* const qs = reinterpret_cast<sbf16x8*>(qs_raw);  // [QB][24 steps][64 lanes]
@@ -846,7 +880,7 @@ __global__ __launch_bounds__(WAVES * 64) void screen_topk_kernel(ScreenParams p)
   __syncthreads();
   const sbf16x8* qlane = qs + lane;
 
-  LaneList<K> list[QB];
+  LaneList<LK> list[QB];
   float gthr[QB];   // best known lower bound on the query's final K-th SCREEN score, minus 2e
   float band[QB];
   int* tau_q[QB];
@@ -866,9 +900,12 @@ __global__ __launch_bounds__(WAVES * 64) void screen_topk_kernel(ScreenParams p)
   const sbf16x8* lane_base = p.tiled + lane;
   const bool ragged = (p.n_rows & 31) != 0;
 
-  sbf16x8 bufA[BGROUP], bufB[BGROUP];
+  sbf16x8 buf[SCREEN_RING][BGROUP];
   int t = t_begin + wave;
-  if (t < t_end) load_bgroup(bufA, lane_base + (int64_t)t * BTILE_VEC);
+  if (t < t_end) {
+#pragma unroll
+    for (int g = 0; g + 1 < SCREEN_RING; ++g) load_bgroup(buf[g], lane_base + (int64_t)t * BTILE_VEC + g * BGROUP * 64);
+  }
 
   int tiles_done = 0;
   for (; t < t_end; t += WAVES, ++tiles_done) {
@@ -895,15 +932,7 @@ __global__ __launch_bounds__(WAVES * 64) void screen_topk_kernel(ScreenParams p)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[qq][r] = 0.f;
 
-    load_bgroup(bufB, tile + 1 * BGROUP * 64);
-    compute_bgroup<QB, 0>(bufA, qlane, acc);
-    load_bgroup(bufA, tile + 2 * BGROUP * 64);
-    compute_bgroup<QB, 1>(bufB, qlane, acc);
-    if (t + WAVES < t_end) load_bgroup(bufB, tile + (int64_t)WAVES * BTILE_VEC);
-    compute_bgroup<QB, 2>(bufA, qlane, acc);
-    // the next tile's first group sits in bufB: swap roles by copying (8 registers x 4)
-#pragma unroll
-    for (int s = 0; s < BGROUP; ++s) bufA[s] = bufB[s];
+    screen_tile_groups<QB, 0>(buf, tile, qlane, acc, t + WAVES < t_end, (int64_t)WAVES * BTILE_VEC);
 
     const int rowbase = t * TILE_ROWS + 4 * h;
     if (ragged && t == p.n_tiles - 1) {
@@ -918,13 +947,13 @@ __global__ __launch_bounds__(WAVES * 64) void screen_topk_kernel(ScreenParams p)
       float m = acc[qq][0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[qq][r]);
-      if (__any(m > list[qq].s[K - 1] && m >= gthr[qq])) {
+      if (__any(m > list[qq].s[LK - 1] && m >= gthr[qq])) {
         bool grew = false;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float x = acc[qq][r];
           const int xid = rowbase + (r & 3) + 8 * (r >> 2);
-          const bool take = x > list[qq].s[K - 1] && x >= gthr[qq];
+          const bool take = x > list[qq].s[LK - 1] && x >= gthr[qq];
           if (__any(take)) {
             if (take) {
               list[qq].insert(x, xid);
@@ -951,9 +980,9 @@ __global__ __launch_bounds__(WAVES * 64) void screen_topk_kernel(ScreenParams p)
   for (int qq = 0; qq < QB; ++qq) {
     const int q = q0 + qq * 32 + j;
     if (q < p.nq) {
-      const int64_t base = ((int64_t)q * p.lists_per_query + (slice * WAVES + wave) * 2 + h) * K;
+      const int64_t base = ((int64_t)q * p.lists_per_query + (slice * WAVES + wave) * 2 + h) * LK;
 #pragma unroll
-      for (int i = 0; i < K; ++i) {
+      for (int i = 0; i < LK; ++i) {
         p.part_scores[base + i] = list[qq].s[i];
         p.part_ids[base + i] = list[qq].id[i];
       }
@@ -1688,16 +1717,16 @@ bool screen_plan(int64_t n_rows, int nq, int k, ScreenPlan* sp) {
   pl.n_qblocks = (int)sskd::ceil_div(nq, 32 * pl.QB);
   int slices = (int)sskd::ceil_div(1024, pl.n_qblocks);
   slices = (int)sskd::ceil_div(slices, 8) * 8;
-  const int max_by_lists = SCREEN_MAX_ENTRIES / (10 * 16);       // lists = slices * 8 waves * 2
+  const int max_by_lists = SCREEN_MAX_ENTRIES / (SCREEN_LISTK * 2 * SCREEN_WAVES);  // lists = slices * waves * 2
   if (slices > max_by_lists) slices = max_by_lists / 8 * 8;
-  const int max_slices = (int)sskd::ceil_div(pl.n_tiles, 8);
+  const int max_slices = (int)sskd::ceil_div(pl.n_tiles, SCREEN_WAVES);
   if (slices > max_slices) slices = max_slices;
   if (slices < 1) slices = 1;
   pl.tiles_per_slice = (int)sskd::ceil_div(pl.n_tiles, slices);
   pl.n_slices = (int)sskd::ceil_div(pl.n_tiles, pl.tiles_per_slice);
-  pl.lists_per_query = pl.n_slices * 8 * 2;
-  if (pl.lists_per_query * 10 > SCREEN_MAX_ENTRIES) return false;
-  pl.part_elems = (size_t)nq * pl.lists_per_query * 10;
+  pl.lists_per_query = pl.n_slices * SCREEN_WAVES * 2;
+  if (pl.lists_per_query * SCREEN_LISTK > SCREEN_MAX_ENTRIES) return false;
+  pl.part_elems = (size_t)nq * pl.lists_per_query * SCREEN_LISTK;
   *sp = pl;
   return true;
 }
@@ -1808,13 +1837,13 @@ int sskd_index_search_screened(const float* d_tiled, const void* d_bf16, int64_t
   const size_t lds = (size_t)pl.QB * BSTEPS * 64 * 16 + (size_t)pl.QB * 32 * 11 * sizeof(int);
   if (ev_scan_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_scan_begin), st);
   if (pl.QB == 4) {
-    auto kern = screen_topk_kernel<10, 4, 8>;
+    auto kern = screen_topk_kernel<10, 4, SCREEN_WAVES>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(pl.n_qblocks * pl.n_slices), dim3(512), lds, st, sp);
+    hipLaunchKernelGGL(kern, dim3(pl.n_qblocks * pl.n_slices), dim3(SCREEN_WAVES * 64), lds, st, sp);
   } else {
-    auto kern = screen_topk_kernel<10, 2, 8>;
+    auto kern = screen_topk_kernel<10, 2, SCREEN_WAVES>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(pl.n_qblocks * pl.n_slices), dim3(512), lds, st, sp);
+    hipLaunchKernelGGL(kern, dim3(pl.n_qblocks * pl.n_slices), dim3(SCREEN_WAVES * 64), lds, st, sp);
   }
   if (ev_scan_end) (void)hipEventRecord(static_cast<hipEvent_t>(ev_scan_end), st);
   int rc = sskd::check_launch("screen_topk_kernel");
@@ -1826,7 +1855,7 @@ int sskd_index_search_screened(const float* d_tiled, const void* d_bf16, int64_t
   fp.eps2 = w.eps2;
   fp.tiled = d_tiled;
   fp.queries = d_queries;
-  fp.K = 10;
+  fp.K = SCREEN_LISTK;
   fp.lists = pl.lists_per_query;
   fp.k = k;
   fp.nq = nq;

@@ -19,7 +19,7 @@ for f in sorted(root.rglob("*counter_collection.csv")):
         d[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     print(f"== {f.relative_to(root)}")
     for k, cs in d.items():
-        if not any(x in k for x in ("mlp", "attention", "gemm_n384", "scan_topk")):
+        if not any(x in k for x in ("mlp", "attention", "gemm_n384", "scan_topk", "screen_", "gemm_nt")):
             continue
         print("  " + k)
         for c, v in cs.items():
