@@ -1006,46 +1006,35 @@ struct ScreenFinalParams {
   int* status;                // [1] pre-zeroed: 1 = more unproven queries than the fallback holds
 };
 
-// block-wide "best entry ranking strictly after (bs, bi)" over per-thread candidates
-__device__ inline void block_argbest(float& s, int& i, float* red_s, int* red_i) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// wave-wide arg-best in rank order (higher score, then lower id); i < 0 = nothing
+__device__ inline void wave_argbest(float& s, int& i) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const float os = __shfl_xor(s, o);
     const int oi = __shfl_xor(i, o);
     if (oi >= 0 && (i < 0 || ranks_before(os, oi, s, i))) { s = os; i = oi; }
   }
-  if (lane == 0) { red_s[wave] = s; red_i[wave] = i; }
-  __syncthreads();
-  s = red_s[0];
-  i = red_i[0];
-#pragma unroll
-  for (int w = 1; w < 4; ++w)
-    if (red_i[w] >= 0 && (i < 0 || ranks_before(red_s[w], red_i[w], s, i))) { s = red_s[w]; i = red_i[w]; }
-  __syncthreads();
 }
 
-// One workgroup (256 threads) per query: k-th best screen score -> candidate band -> proof that no
-// list truncated the band -> exact re-scoring (the fp32 MFMA's k-ordered fma chain) -> exact top k.
-__global__ __launch_bounds__(256) void screen_finalize_kernel(ScreenFinalParams p) {
-  __shared__ float es[SCREEN_MAX_ENTRIES];
-  __shared__ int ei[SCREEN_MAX_ENTRIES];
-  __shared__ __attribute__((aligned(16))) float qv[DIM];
-  __shared__ float cs[SCREEN_MAX_CAND];
-  __shared__ int ci[SCREEN_MAX_CAND];
-  __shared__ float red_s[4];
-  __shared__ int red_i[4];
-  __shared__ int n_cand, unproven;
-  const int q = blockIdx.x, tid = threadIdx.x;
+// One WAVE per query (no workgroup barriers; 12 KiB of LDS at the bench shape, so a dozen queries
+// per CU are in flight): k-th best screen score -> candidate band -> proof that no list truncated
+// the band -> exact re-scoring (the fp32 MFMA's k-ordered fma chain) -> exact top k.
+// Dynamic LDS: [L] scores, [L] ids, [384] query, [SCREEN_MAX_CAND] candidate rows.
+__global__ __launch_bounds__(64) void screen_finalize_kernel(ScreenFinalParams p) {
+  extern __shared__ __attribute__((aligned(16))) float fin_lds[];
   const int L = p.lists * p.K;
+  float* const es = fin_lds;
+  int* const ei = reinterpret_cast<int*>(fin_lds + L);
+  float* const qv = fin_lds + 2 * L;
+  int* const ci = reinterpret_cast<int*>(qv + DIM);
+  const int q = blockIdx.x, lane = threadIdx.x;
   const int64_t base = (int64_t)q * L;
-  for (int e = tid; e < L; e += 256) {
+  for (int e = lane; e < L; e += 64) {
     es[e] = p.part_scores[base + e];
     ei[e] = p.part_ids[base + e];
   }
-  for (int c = tid; c < DIM; c += 256) qv[c] = p.queries[(int64_t)q * DIM + c];
-  if (tid == 0) { n_cand = 0; unproven = 0; }
-  __syncthreads();
+  for (int c = lane; c < DIM; c += 64) qv[c] = p.queries[(int64_t)q * DIM + c];
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): one wave, its own LDS writes
 
   // k-th best screen entry in rank order (k rounds of bounded arg-best)
   float bs = INFINITY;
@@ -1056,14 +1045,14 @@ __global__ __launch_bounds__(256) void screen_finalize_kernel(ScreenFinalParams 
   for (int r = 0; r < p.k; ++r) {
     float s = -INFINITY;
     int i = -1;
-    for (int e = tid; e < L; e += 256) {
+    for (int e = lane; e < L; e += 64) {
       const int id = ei[e];
       if (id < 0) continue;
       const float v = es[e];
       if (have && !ranks_before(bs, bi, v, id)) continue;
       if (i < 0 || ranks_before(v, id, s, i)) { s = v; i = id; }
     }
-    block_argbest(s, i, red_s, red_i);
+    wave_argbest(s, i);
     if (i < 0) break;
     bs = s; bi = i; have = true;
     kth = s;
@@ -1073,72 +1062,87 @@ __global__ __launch_bounds__(256) void screen_finalize_kernel(ScreenFinalParams 
   const float tau = found == p.k ? kth - p.eps2[q] : -INFINITY;
 
   // proof: a FULL list whose last entry is still inside the band may have dropped candidates
-  for (int l = tid; l < p.lists; l += 256) {
+  bool bad = false;
+  for (int l = lane; l < p.lists; l += 64) {
     const int e = l * p.K + p.K - 1;
-    if (ei[e] >= 0 && es[e] >= tau) unproven = 1;
+    if (ei[e] >= 0 && es[e] >= tau) bad = true;
   }
-  for (int e = tid; e < L; e += 256) {
-    if (ei[e] >= 0 && es[e] >= tau) {
-      const int slot = atomicAdd(&n_cand, 1);
+  // candidates, compacted in entry order (ballot prefix)
+  int M = 0;
+  for (int e0 = 0; e0 < L; e0 += 64) {
+    const int e = e0 + lane;
+    const bool in = e < L && ei[e] >= 0 && es[e] >= tau;
+    const unsigned long long mask = __ballot(in);
+    if (in) {
+      const int slot = M + __popcll(mask & ((1ull << lane) - 1ull));
       if (slot < SCREEN_MAX_CAND) ci[slot] = ei[e];
     }
+    M += __popcll(mask);
   }
-  __syncthreads();
-  if (n_cand > SCREEN_MAX_CAND) unproven = 1;
-  __syncthreads();
-  if (unproven) {
-    __shared__ int slot_s;
-    if (tid == 0) {
-      slot_s = atomicAdd(p.fb_count, 1);
-      if (slot_s < SCREEN_FALLBACK_CAP) p.fb_qid[slot_s] = q;
+  if (M > SCREEN_MAX_CAND) bad = true;
+  if (__any(bad)) {
+    int slot = 0;
+    if (lane == 0) {
+      slot = atomicAdd(p.fb_count, 1);
+      if (slot < SCREEN_FALLBACK_CAP) p.fb_qid[slot] = q;
       else atomicMax(p.status, 1);
     }
-    __syncthreads();
-    const int slot = slot_s;
+    slot = __shfl(slot, 0);
     if (slot < SCREEN_FALLBACK_CAP) {
-      for (int c = tid; c < DIM; c += 256) p.fb_queries[(int64_t)slot * DIM + c] = qv[c];
+      for (int c = lane; c < DIM; c += 64) p.fb_queries[(int64_t)slot * DIM + c] = qv[c];
     } else {
-      for (int r = tid; r < p.k; r += 256) {  // loud, never plausible
+      for (int r = lane; r < p.k; r += 64) {  // loud, never plausible
         p.out_scores[(int64_t)q * p.k + r] = __int_as_float(0x7fc00000);
         p.out_ids[(int64_t)q * p.k + r] = -2;
       }
     }
     return;
   }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
 
-  // exact score of candidate `tid`: the fma order of the 32x32x2 f32 MFMA chain
-  const int M = n_cand;
-  float my_s = -INFINITY;
-  int my_i = -1;
-  if (tid < M) {
-    const int row = ci[tid];
-    const float4* src = reinterpret_cast<const float4*>(p.tiled) + (int64_t)(row >> 5) * (TILE_ROWS * CHUNKS) + (row & 31);
-    float acc = 0.f;
+  // exact scores, 64 candidates per round: the fma order of the 32x32x2 f32 MFMA chain (section 3.1).
+  // Each lane keeps the best (up to 4) of its own candidates; M <= 256.
+  float cs[SCREEN_MAX_CAND / 64];
+  int cid[SCREEN_MAX_CAND / 64];
+#pragma unroll
+  for (int c = 0; c < SCREEN_MAX_CAND / 64; ++c) {
+    cs[c] = -INFINITY;
+    cid[c] = -1;
+    const int idx = c * 64 + lane;
+    if (idx < M) {
+      const int row = ci[idx];
+      const float4* src = reinterpret_cast<const float4*>(p.tiled) + (int64_t)(row >> 5) * (TILE_ROWS * CHUNKS) + (row & 31);
+      float acc = 0.f;
 #pragma unroll 4
-    for (int u = 0; u < STEPS; ++u) {
-      const float4 a = src[u * 64], b = src[u * 64 + 32];
-      const float4 qa = *reinterpret_cast<const float4*>(&qv[8 * u]), qb = *reinterpret_cast<const float4*>(&qv[8 * u + 4]);
-      acc = fmaf(a.x, qa.x, acc); acc = fmaf(b.x, qb.x, acc);
-      acc = fmaf(a.y, qa.y, acc); acc = fmaf(b.y, qb.y, acc);
-      acc = fmaf(a.z, qa.z, acc); acc = fmaf(b.z, qb.z, acc);
-      acc = fmaf(a.w, qa.w, acc); acc = fmaf(b.w, qb.w, acc);
+      for (int u = 0; u < STEPS; ++u) {
+        const float4 a = src[u * 64], b = src[u * 64 + 32];
+        const float4 qa = *reinterpret_cast<const float4*>(&qv[8 * u]), qb = *reinterpret_cast<const float4*>(&qv[8 * u + 4]);
+        acc = fmaf(a.x, qa.x, acc); acc = fmaf(b.x, qb.x, acc);
+        acc = fmaf(a.y, qa.y, acc); acc = fmaf(b.y, qb.y, acc);
+        acc = fmaf(a.z, qa.z, acc); acc = fmaf(b.z, qb.z, acc);
+        acc = fmaf(a.w, qa.w, acc); acc = fmaf(b.w, qb.w, acc);
+      }
+      cs[c] = acc;
+      cid[c] = (acc == acc) ? row : -1;  // a NaN score is never selected (as in the exact scan)
     }
-    my_s = acc;
-    my_i = row;
-    if (!(acc == acc)) my_i = -1;  // a NaN score is never selected (as in the exact scan)
   }
   bs = INFINITY; bi = -1; have = false;
   for (int r = 0; r < p.k; ++r) {
-    float s = my_s;
-    int i = my_i;
-    if (i >= 0 && have && !ranks_before(bs, bi, s, i)) i = -1;
-    block_argbest(s, i, red_s, red_i);
-    if (tid == 0) {
+    float s = -INFINITY;
+    int i = -1;
+#pragma unroll
+    for (int c = 0; c < SCREEN_MAX_CAND / 64; ++c) {
+      if (cid[c] < 0) continue;
+      if (have && !ranks_before(bs, bi, cs[c], cid[c])) continue;
+      if (i < 0 || ranks_before(cs[c], cid[c], s, i)) { s = cs[c]; i = cid[c]; }
+    }
+    wave_argbest(s, i);
+    if (lane == 0) {
       p.out_scores[(int64_t)q * p.k + r] = i >= 0 ? s : -FLT_MAX;
       p.out_ids[(int64_t)q * p.k + r] = i >= 0 ? (int64_t)i + p.id_offset : -1;
     }
     if (i < 0) {
-      for (int rr = r + 1 + tid; rr < p.k; rr += 256) {
+      for (int rr = r + 1 + lane; rr < p.k; rr += 64) {
         p.out_scores[(int64_t)q * p.k + rr] = -FLT_MAX;
         p.out_ids[(int64_t)q * p.k + rr] = -1;
       }
@@ -1715,12 +1719,18 @@ bool screen_plan(int64_t n_rows, int nq, int k, ScreenPlan* sp) {
   pl.n_tiles = (int)sskd::ceil_div(n_rows, TILE_ROWS);
   pl.QB = nq >= 256 ? 4 : 2;
   pl.n_qblocks = (int)sskd::ceil_div(nq, 32 * pl.QB);
-  int slices = (int)sskd::ceil_div(1024, pl.n_qblocks);
+#ifndef SSKD_SCREEN_TARGET_WGS
+#define SSKD_SCREEN_TARGET_WGS 1024
+#endif
+  int slices = (int)sskd::ceil_div(SSKD_SCREEN_TARGET_WGS, pl.n_qblocks);
   slices = (int)sskd::ceil_div(slices, 8) * 8;
   const int max_by_lists = SCREEN_MAX_ENTRIES / (SCREEN_LISTK * 2 * SCREEN_WAVES);  // lists = slices * waves * 2
   if (slices > max_by_lists) slices = max_by_lists / 8 * 8;
   const int max_slices = (int)sskd::ceil_div(pl.n_tiles, SCREEN_WAVES);
   if (slices > max_slices) slices = max_slices;
+  // a wave needs a few dozen tiles to amortise filling its lists and warming the pools: on small
+  // shards (the 8-GPU shard of cfg 2 is 125 k rows) fewer, longer slices win (2.46 -> 2.12 ms)
+  while (slices > 8 && pl.n_tiles / (slices * SCREEN_WAVES) < 48) slices -= 8;
   if (slices < 1) slices = 1;
   pl.tiles_per_slice = (int)sskd::ceil_div(pl.n_tiles, slices);
   pl.n_slices = (int)sskd::ceil_div(pl.n_tiles, pl.tiles_per_slice);
@@ -1866,7 +1876,8 @@ int sskd_index_search_screened(const float* d_tiled, const void* d_bf16, int64_t
   fp.fb_qid = w.fb_qid;
   fp.fb_queries = w.fb_queries;
   fp.status = d_status;
-  hipLaunchKernelGGL(screen_finalize_kernel, dim3(nq), dim3(256), 0, st, fp);
+  const size_t fin_lds = ((size_t)2 * pl.lists_per_query * SCREEN_LISTK + DIM + SCREEN_MAX_CAND) * sizeof(float);
+  hipLaunchKernelGGL(screen_finalize_kernel, dim3(nq), dim3(64), fin_lds, st, fp);
   if ((rc = sskd::check_launch("screen_finalize_kernel")) != SSKD_OK) return rc;
 
   // exact scan for the queries whose candidate band could not be proven complete (usually none:
