@@ -122,3 +122,31 @@ def test_product_search_device_uses_screening_and_matches_exact(gpu, native_lib)
     s4, i4 = index.search_device(q[:10], 20)
     ref = oracle.topk_fma(queries[:10], corpus, 20, 7)
     assert np.array_equal(i4.cpu().numpy(), ref[1])
+
+
+@pytest.mark.parametrize("n,nq", [(1_000_000, 10_000), (8_841_823, 1_024)])
+def test_screened_equals_exact_scan_at_full_size(gpu, native_lib, n, nq):
+    """BASELINE cfg 2 / cfg 3 sizes: every output row of the screened search equals the exact scan's
+    (GPU vs GPU, all queries, bit for bit); the exact scan itself is held to the oracle elsewhere."""
+    gen = torch.Generator(device="cuda").manual_seed(1234)
+    index = FAISSIndexBuilder(embedding_dim=384, metric="ip", device="cuda:0", id_offset=11)
+    index.reserve(n)
+    first = None
+    for lo in range(0, n, 1 << 20):
+        rows = torch.randn((min(1 << 20, n - lo), 384), generator=gen, device="cuda", dtype=torch.float32)
+        rows /= rows.norm(dim=1, keepdim=True)
+        if first is None:
+            first = rows[:4096].clone()
+        index.add(rows)
+    del rows
+    q = torch.randn((nq, 384), generator=gen, device="cuda", dtype=torch.float32)
+    q[::16] = first[: (nq + 15) // 16] + 0.02 * q[::16]     # near-duplicates of corpus rows among the queries
+    q /= q.norm(dim=1, keepdim=True)
+    s1, i1 = index.search_device(q, 10, normalize_queries=False)
+    status = index.last_status.cpu().numpy()
+    assert status[0] == 0
+    index.screening = False
+    s2, i2 = index.search_device(q, 10, normalize_queries=False)
+    assert index.last_status is None
+    assert torch.equal(i1, i2) and torch.equal(s1, s2)
+    assert int(i1.min()) >= 11 and (torch.diff(s1, dim=1) <= 0).all()
