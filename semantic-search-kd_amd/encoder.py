@@ -159,10 +159,12 @@ class Mi355xSentenceEncoder:
             max_seq_length or st_max or min(512, self.config.max_position_embeddings)
         )
         self._workspace: Optional[torch.Tensor] = None
+        self._workspace2: Optional[torch.Tensor] = None   # second half of a split batch (side stream)
+        self._side_stream: Optional[torch.cuda.Stream] = None
+        self.split_streams = True   # large batches / alternate launches over two HIP streams
         self._staging: List[_Staging] = []
         self._stage_next = 0
-        self._rows_ids: Optional[torch.Tensor] = None
-        self._rows_seg: Optional[torch.Tensor] = None
+        self._rows: list = [None, None]   # per stream lane: (packed ids, segment words)
         self._tok_pool: Optional[ThreadPoolExecutor] = None
         self.last_encode_stats: Dict[str, float] = {}
 
@@ -275,10 +277,32 @@ class Mi355xSentenceEncoder:
             out = torch.empty((B, self.config.hidden_size), dtype=torch.float32, device=self.device)
         if B == 0:
             return out
+        if self.split_streams and B >= 512 and B % 2 == 0 and S <= 256:
+            # Two halves on two HIP streams: the load/store-bound output projection of one half runs
+            # beside the matrix-bound fused MLP of the other (same work, 5-6 % less time at 512 x 256).
+            # Fork / join with events: the caller's stream semantics are unchanged.
+            h = B // 2
+            main = torch.cuda.current_stream(self.device)
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(self.device)
+            side = self._side_stream
+            side.wait_stream(main)
+            self._forward_rows(lib, ids[:h], mask[:h], normalize, out[:h], main, "_workspace")
+            with torch.cuda.stream(side):
+                self._forward_rows(lib, ids[h:], mask[h:], normalize, out[h:], side, "_workspace2")
+            main.wait_stream(side)
+            return out
+        self._forward_rows(lib, ids, mask, normalize, out, torch.cuda.current_stream(self.device), "_workspace")
+        return out
+
+    def _forward_rows(self, lib, ids, mask, normalize, out, stream, ws_name: str) -> None:
+        B, S = ids.shape
         need = int(lib.sskd_encoder_workspace_bytes(self.weights.cstruct_cfg, B, S))
-        if self._workspace is None or self._workspace.numel() < need:
-            self._workspace = None
-            self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        ws = getattr(self, ws_name)
+        if ws is None or ws.numel() < need:
+            setattr(self, ws_name, None)
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            setattr(self, ws_name, ws)
         _native.check(
             lib.sskd_encoder_forward(
                 self.weights.cstruct_cfg,
@@ -289,19 +313,17 @@ class Mi355xSentenceEncoder:
                 S,
                 int(bool(normalize)),
                 out.data_ptr(),
-                self._workspace.data_ptr(),
-                self._workspace.numel(),
-                int(torch.cuda.current_stream(self.device).cuda_stream),
+                ws.data_ptr(),
+                ws.numel(),
+                int(stream.cuda_stream),
             )
         )
-        return out
-
 
     # ------------------------------------------------------------ packed varlen path
     def _stage(self, words: int) -> _Staging:
         if not self._staging or self._staging[0].host.numel() < words:
             size = max(words, LAUNCH_TOKENS + 5 * (LAUNCH_TOKENS // 8) + 64)
-            self._staging = [_Staging(self.device, size) for _ in range(3)]
+            self._staging = [_Staging(self.device, size) for _ in range(4)]
             self._stage_next = 0
         st = self._staging[self._stage_next]
         self._stage_next = (self._stage_next + 1) % len(self._staging)
@@ -332,10 +354,17 @@ class Mi355xSentenceEncoder:
         np.cumsum(lengths, out=cu[1:])
         if int(cu[-1]) != flat_ids.shape[0]:
             raise ValueError("encode_ragged: flat_ids does not hold sum(lengths) tokens")
-        stream = int(torch.cuda.current_stream(self.device).cuda_stream)
+        # launches alternate between the caller's stream and a side stream (fork / join with events):
+        # the load/store-bound kernels of one launch run beside the matrix-bound ones of the other
+        main = torch.cuda.current_stream(self.device)
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(self.device)
+        lanes = [main, self._side_stream if self.split_streams else main]
+        self._side_stream.wait_stream(main)
         budget = int(LAUNCH_TOKENS * 0.97)
         padded_tokens = 0
         s0 = 0
+        launch = 0
         while s0 < n:
             s1 = int(np.searchsorted(cu, cu[s0] + budget, side="right")) - 1
             s1 = min(max(s1, s0 + 1), n)
@@ -351,31 +380,40 @@ class Mi355xSentenceEncoder:
             _native.check(lib.sskd_pack_plan(lengths[s0:s1].ctypes.data, m, cap, table.ctypes.data, n_rows))
             rows = n_rows.value
             words = total + (m + 1) + 4 * m
-            st.dev[:words].copy_(st.host[:words], non_blocking=True)
-            st.done.record(torch.cuda.current_stream(self.device))
-            st.used = True
-            need_rows = rows * cap
-            if self._rows_ids is None or self._rows_ids.numel() < need_rows:
-                size = max(need_rows, LAUNCH_TOKENS + 16 * ROW_CAPACITY)
-                self._rows_ids = torch.empty(size, dtype=torch.int32, device=self.device)
-                self._rows_seg = torch.empty(size, dtype=torch.int32, device=self.device)
-            base = st.dev.data_ptr()
-            d_cu, d_table = base + 4 * total, base + 4 * (total + m + 1)
-            _native.check(lib.sskd_pack_tokens(base, d_cu, d_table, m, rows, cap, self._rows_ids.data_ptr(),
-                                               self._rows_seg.data_ptr(), stream))
-            need = int(lib.sskd_encoder_workspace_bytes(self.weights.cstruct_cfg, rows, cap))
-            if self._workspace is None or self._workspace.numel() < need:
-                self._workspace = None
-                self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
-            _native.check(
-                lib.sskd_encoder_forward_packed(
-                    self.weights.cstruct_cfg, self.weights.struct, self._rows_ids.data_ptr(), self._rows_seg.data_ptr(),
-                    rows, cap, d_table, m, int(bool(normalize)), out[s0:].data_ptr(),
-                    self._workspace.data_ptr(), self._workspace.numel(), stream,
+            lane = launch & 1
+            with torch.cuda.stream(lanes[lane]):
+                stream = int(lanes[lane].cuda_stream)
+                st.dev[:words].copy_(st.host[:words], non_blocking=True)
+                st.done.record(lanes[lane])
+                st.used = True
+                need_rows = rows * cap
+                if self._rows[lane] is None or self._rows[lane][0].numel() < need_rows:
+                    size = max(need_rows, LAUNCH_TOKENS + 16 * ROW_CAPACITY)
+                    self._rows[lane] = (torch.empty(size, dtype=torch.int32, device=self.device),
+                                        torch.empty(size, dtype=torch.int32, device=self.device))
+                rows_ids, rows_seg = self._rows[lane]
+                base = st.dev.data_ptr()
+                d_cu, d_table = base + 4 * total, base + 4 * (total + m + 1)
+                _native.check(lib.sskd_pack_tokens(base, d_cu, d_table, m, rows, cap, rows_ids.data_ptr(),
+                                                   rows_seg.data_ptr(), stream))
+                need = int(lib.sskd_encoder_workspace_bytes(self.weights.cstruct_cfg, rows, cap))
+                ws_name = "_workspace" if lane == 0 else "_workspace2"
+                ws = getattr(self, ws_name)
+                if ws is None or ws.numel() < need:
+                    setattr(self, ws_name, None)
+                    ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                    setattr(self, ws_name, ws)
+                _native.check(
+                    lib.sskd_encoder_forward_packed(
+                        self.weights.cstruct_cfg, self.weights.struct, rows_ids.data_ptr(), rows_seg.data_ptr(),
+                        rows, cap, d_table, m, int(bool(normalize)), out[s0:].data_ptr(),
+                        ws.data_ptr(), ws.numel(), stream,
+                    )
                 )
-            )
             padded_tokens += rows * cap
             s0 = s1
+            launch += 1
+        main.wait_stream(self._side_stream)
         self.last_encode_stats = {"real_tokens": float(cu[-1]), "padded_tokens": float(padded_tokens),
                                   "padding_overhead": padded_tokens / float(cu[-1]) - 1.0}
         return out
@@ -504,7 +542,8 @@ class Mi355xSentenceEncoder:
 
     def cleanup(self) -> None:
         self._workspace = None
-        self._staging, self._rows_ids, self._rows_seg = [], None, None
+        self._workspace2 = None
+        self._staging, self._rows = [], [None, None]
         if self._tok_pool is not None:
             self._tok_pool.shutdown(wait=True)
             self._tok_pool = None
