@@ -330,8 +330,9 @@ def main() -> None:
     if use_screen:
         # screening kernel: bf16 MFMA (32x32x16) over a bf16 copy of the rows; B_q = 128 queries per workgroup
         assert int(status[0].item()) == 0, "screened search overflowed its exact fallback"
-        qpb_v, passes_v = (128 if nq >= 256 else 64), -(-nq // (128 if nq >= 256 else 64))
-        slices_v = None
+        qpb, passes, slices = (C.c_int() for _ in range(3))
+        _native.check(lib.sskd_index_search_screened_plan(n_local, nq, K, qpb, passes, slices))
+        qpb_v, passes_v, slices_v = qpb.value, passes.value, slices.value
         alg_bytes = passes_v * n_local * DIM * 2 + nq * DIM * 4 + nq * K * 12
         kernel_name, peak_tf = "screen_topk_kernel", MFMA_BF16_PEAK_TF
         tpath = REPO / "profiles" / "screen_traffic.json"

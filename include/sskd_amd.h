@@ -138,6 +138,9 @@ int sskd_index_search_profiled(const float* d_tiled, int64_t n_rows,
 size_t sskd_index_bf16_bytes(int64_t n_rows);
 int sskd_index_make_bf16(const float* d_tiled, int64_t n_rows, void* d_bf16, void* stream);
 size_t sskd_index_search_screened_workspace_bytes(int64_t n_rows, int nq, int k);
+/* launch geometry of the screening pass (roofline accounting): queries per workgroup, corpus passes, slices */
+int sskd_index_search_screened_plan(int64_t n_rows, int nq, int k, int* queries_per_block, int* corpus_passes,
+                                    int* n_slices);
 int sskd_index_search_screened(const float* d_tiled, const void* d_bf16, int64_t n_rows, const float* d_queries,
                                int nq, int k, int64_t id_offset, float* d_out_scores, int64_t* d_out_ids,
                                int* d_status, void* d_workspace, size_t workspace_bytes, void* stream,

@@ -1717,7 +1717,9 @@ bool screen_plan(int64_t n_rows, int nq, int k, ScreenPlan* sp) {
   if (k < 1 || k > 10 || nq < 64 || n_rows < 64 * TILE_ROWS) return false;
   ScreenPlan pl{};
   pl.n_tiles = (int)sskd::ceil_div(n_rows, TILE_ROWS);
-  pl.QB = nq >= 256 ? 4 : 2;
+  // 128 queries per workgroup cut the corpus re-reads in half; shards small enough to live in L2 /
+  // Infinity Cache do better with twice the workgroups (64 queries each, 2-3 resident per CU)
+  pl.QB = (nq >= 256 && pl.n_tiles >= 8192) ? 4 : 2;
   pl.n_qblocks = (int)sskd::ceil_div(nq, 32 * pl.QB);
 #ifndef SSKD_SCREEN_TARGET_WGS
 #define SSKD_SCREEN_TARGET_WGS 1024
@@ -1796,6 +1798,16 @@ int sskd_index_make_bf16(const float* d_tiled, int64_t n_rows, void* d_bf16, voi
   hipLaunchKernelGGL(make_bf16_tiles_kernel, dim3((unsigned)tiles), dim3(256), 0, st,
                      reinterpret_cast<const float4*>(d_tiled), tiles, static_cast<sbf16x8*>(d_bf16), max_norm2);
   return sskd::check_launch("make_bf16_tiles_kernel");
+}
+
+int sskd_index_search_screened_plan(int64_t n_rows, int nq, int k, int* queries_per_block, int* corpus_passes,
+                                    int* n_slices) {
+  ScreenPlan pl{};
+  if (!screen_plan(n_rows, nq, k, &pl)) return sskd::fail(SSKD_ERR_UNSUPPORTED, "index_search_screened_plan: shape not served");
+  if (queries_per_block) *queries_per_block = 32 * pl.QB;
+  if (corpus_passes) *corpus_passes = pl.n_qblocks;
+  if (n_slices) *n_slices = pl.n_slices;
+  return SSKD_OK;
 }
 
 size_t sskd_index_search_screened_workspace_bytes(int64_t n_rows, int nq, int k) {
