@@ -23,6 +23,10 @@ __device__ inline float wave_max(float v) {
 
 // ------------------------------------------------------------------------- //
 // NT GEMM: 128 x 128 block tile, 4 waves as 2 x 2, each wave 64 x 64 = 2 x 2 MFMA tiles.
+// (A 128 x 256 block tile - wave tile 64 x 128, 6 fragment reads per 8 MFMAs - was built and measured:
+// its 66 KiB of LDS leave 2 workgroups per CU instead of 4, and this two-barrier loop lives on
+// occupancy: teacher 3 390 -> 2 860 pairs/s, KD step 60 -> 209 ms.  Bigger tiles need the counted-wait
+// double-buffered structure first.)
 // Operand tiles go global -> registers -> LDS (rows padded by 16 B: conflict-free ds_read_b128),
 // the next tile's global loads are in flight while the current one is multiplied.
 // ------------------------------------------------------------------------- //
