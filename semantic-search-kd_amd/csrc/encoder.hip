@@ -24,8 +24,8 @@
 //
 // Kernels per layer (hidden 384, 12 heads x 32, FFN 1536):
 //   qkv_attention_kernel    ctx = softmax((X Wq^T)(X Wk^T)^T / sqrt(32) + mask)(X Wv^T)   (Q, K, V stay on chip)
-//   gemm_n384_ln_kernel<2>  X1 = LN(X  + ctx Wo^T + bo)
-//   fused_mlp_ln_kernel     X2 = LN(X1 + gelu(X1 W1^T + b1) W2^T + b2)   (hidden 1536 stays on chip)
+//   fused_mlp_ln_kernel     X1 = LN(X  + ctx Wo^T + bo)                      (prologue; X1 stays on chip)
+//                           X2 = LN(X1 + gelu(X1 W1^T + b1) W2^T + b2)       (hidden 1536 stays on chip)
 #include "common.h"
 
 #include <type_traits>
@@ -284,10 +284,12 @@ constexpr int HTILE_VEC = 32 * 192 / 8;  // bf16x8 vectors of one [32 x 192] wei
 // nothing).  Every wave of the workgroup must call this (it contains workgroup barriers).
 constexpr int GEMM384_WL_VEC = 2 * 2 * 2 * HTILE_VEC;  // bf16x8 vectors of the weight staging area
 
-template <int KC2>
+// OUT_LDS: the normalised rows are written as a fragment-order image of the 4 token tiles into `img`
+// (which may alias `wl`: the weight buffers are dead by then) instead of p.out.
+template <int KC2, bool OUT_LDS = false>
 __device__ inline void gemm_n384_ln_block(const GemmN384Params& p, int64_t tt0, int n_valid,
                                           bf16x8* __restrict__ wl, float2* __restrict__ stats,
-                                          float* __restrict__ par) {
+                                          float* __restrict__ par, bf16x8* img = nullptr) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -396,17 +398,10 @@ __device__ inline void gemm_n384_ln_block(const GemmN384Params& p, int64_t tt0, 
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[g][e] = (acc[j][4 * g + e] - mean) * rstd * ga[e] + be[e];
       }
-      store_tile_frag(p.out + frag_base(tt, 2 * nt, KSTEPS) * 8, v, lane);
+      if (OUT_LDS) store_tile_frag(reinterpret_cast<__bf16*>(img + frag_base(tg, 2 * nt, KSTEPS)), v, lane);
+      else store_tile_frag(p.out + frag_base(tt, 2 * nt, KSTEPS) * 8, v, lane);
     }
   }
-}
-
-template <int KC2>
-__global__ __launch_bounds__(512) void gemm_n384_ln_kernel(GemmN384Params p) {
-  __shared__ bf16x8 wlds[GEMM384_WL_VEC];  // 96 KiB
-  __shared__ float2 stats[128 * 2];
-  __shared__ __attribute__((aligned(16))) float par_lds[3 * H];  // bias, gamma, beta
-  gemm_n384_ln_block<KC2>(p, (int64_t)blockIdx.x * 4, 4, wlds, stats, par_lds);
 }
 
 // ------------------------------------------------------------------------- //
@@ -422,6 +417,7 @@ struct MlpParams {
   const float* beta;
   float eps;
   __bf16* out;           // fragment-order [T_pad, 384]
+  GemmN384Params outp;   // FUSE_OUTPROJ: X1 = LN(X + ctx Wo^T + bo) is computed in the prologue
 };
 
 constexpr int MLP_CHUNKS = FF / 32;  // 48
@@ -474,9 +470,18 @@ __device__ unsigned long long g_probe[2][64][4];
 // lane r + 32 (g & 1).  The producer finishes e = 0, 1 (dword hp of `hdone`, bf16 pair j = 4hp,
 // 4hp + 1) and passes e = 2, 3 on (floats 2hp, 2hp + 1 of `hraw`, j = 4hp + 2, 4hp + 3): the
 // consumer's fragment is { done.x, pk(raw0, raw1), done.y, pk(raw2, raw3) } - whole dwords only.
+//
+// FUSE_OUTPROJ: the attention output projection + residual + LayerNorm (X1) of the workgroup's 128
+// tokens runs as a PROLOGUE here (gemm_n384_ln_block over the weight buffers, which are idle until
+// the chunk loop starts) and hands X1 over as a fragment-order image in LDS: the producers take their
+// B fragments from it, keep them in registers as before and write them back after the last chunk for
+// the consumers' residual.  X1 never reaches HBM (- 300 MB of traffic per layer at 512 x 256) and
+// the separate, load/store-bound projection kernel disappears.
+template <bool FUSE_OUTPROJ>
 __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
-  __shared__ bf16x8 w1buf[2][WTILE_VEC];          // 2 x 24 KiB (chunk i in i % 2)
-  __shared__ bf16x8 w2buf[2][WTILE_VEC];          // 2 x 24 KiB (chunk i in i % 2)
+  __shared__ bf16x8 wbuf[4][WTILE_VEC];           // W1: [0..1], W2: [2..3] (chunk i in i % 2), 4 x 24 KiB
+  bf16x8 (*const w1buf)[WTILE_VEC] = wbuf;
+  bf16x8 (*const w2buf)[WTILE_VEC] = wbuf + 2;
   __shared__ u32x2 hdone[4][2][64];               // [token tile][fragment][consumer lane]
   __shared__ f32x4 hraw[4][2][64];
   __shared__ __attribute__((aligned(16))) float b1_lds[FF];
@@ -495,6 +500,22 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
     par_lds[1][i] = p.gamma[i];
     par_lds[2][i] = p.beta[i];
   }
+  bf16x8* const x1img = &wbuf[0][0];  // FUSE_OUTPROJ: [4 token tiles][24 k-steps][64 lanes] = 96 KiB
+  if constexpr (FUSE_OUTPROJ) {
+    static_assert(GEMM384_WL_VEC == 4 * WTILE_VEC, "the projection's weight staging area is the MLP's");
+    static_assert(sizeof(hraw) >= 128 * 2 * sizeof(float2) + 3 * H * sizeof(float), "prologue scratch");
+    float2* const stats = reinterpret_cast<float2*>(&hraw[0][0][0]);
+    float* const par = reinterpret_cast<float*>(stats + 128 * 2);
+    gemm_n384_ln_block<2, true>(p.outp, (int64_t)blockIdx.x * 4, 4, x1img, stats, par, x1img);
+    __syncthreads();  // the X1 image is complete
+  }
+  bf16x8 x_pro[KSTEPS];  // producers: the B fragments of this wave's token tile
+  if (producer) {
+    const bf16x8* xs = FUSE_OUTPROJ ? x1img + frag_base(tg, 0, KSTEPS) + lane : p.x1 + frag_base(tt, 0, KSTEPS) + lane;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) x_pro[s] = xs[s * 64];
+  }
+  if constexpr (FUSE_OUTPROJ) __syncthreads();  // everybody has read the image: the buffers are free
   // W1 chunk 0
   for (int i = tid; i < WTILE_VEC; i += 512) w1buf[0][i] = p.w1[i];
   __syncthreads();
@@ -502,12 +523,7 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
   // iterations 0 .. MLP_CHUNKS: the producer's burst is real for it < MLP_CHUNKS, the consumer's
   // for it >= 1; edge phases work on stale data whose results nobody reads (branch-free).
   if (producer) {
-    bf16x8 x[KSTEPS];
-    {
-      const bf16x8* xs = p.x1 + frag_base(tt, 0, KSTEPS) + lane;
-#pragma unroll
-      for (int s = 0; s < KSTEPS; ++s) x[s] = xs[s * 64];
-    }
+    bf16x8 (&x)[KSTEPS] = x_pro;
     // ring of PF + 1 registers: the read issued in slot s targets the register consumed in slot
     // s - 1, never the one the MFMA just issued is still reading (WAR stall)
     constexpr int PF = SSKD_MLP_PF, RING = PF + 1;
@@ -591,6 +607,12 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
       SSKD_STAMP(0, it, 3);
       __syncthreads();
     }
+    if constexpr (FUSE_OUTPROJ) {
+      // the weight buffers are dead: X1 goes back to LDS for the consumers' residual
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) x1img[frag_base(tg, s, KSTEPS) + lane] = x[s];
+      __syncthreads();
+    }
   } else {
     f32x16 y[12];
 #pragma unroll
@@ -656,7 +678,9 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
 
     // epilogue: v = y + b2 + residual; LayerNorm over the token's 384 features (192 in this
     // lane, 192 in lane ^ 32)
-    const __bf16* res = reinterpret_cast<const __bf16*>(p.x1 + frag_base(tt, 0, KSTEPS));
+    if constexpr (FUSE_OUTPROJ) __syncthreads();  // the producers' X1 write-back
+    const __bf16* res = FUSE_OUTPROJ ? reinterpret_cast<const __bf16*>(x1img + frag_base(tg, 0, KSTEPS))
+                                     : reinterpret_cast<const __bf16*>(p.x1 + frag_base(tt, 0, KSTEPS));
     float sum = 0.f, sq = 0.f;
 #pragma unroll
     for (int nt = 0; nt < 12; ++nt)
@@ -1224,7 +1248,7 @@ __global__ __launch_bounds__(256) void untile_hidden_kernel(const __bf16* __rest
 // workspace carve-up
 // ------------------------------------------------------------------------- //
 struct Workspace {
-  __bf16 *xa, *xb, *ctx;
+  __bf16 *xa, *ctx;
   size_t bytes;
 };
 
@@ -1244,7 +1268,6 @@ Workspace carve(void* base, int B, int S) {
     return ptr;
   };
   w.xa = take(T * H);
-  w.xb = take(T * H);
   w.ctx = take(T * H);
   w.bytes = (size_t)(pch - static_cast<char*>(base));
   return w;
@@ -1280,8 +1303,7 @@ int run_layers(const sskd_encoder_config* cfg, const sskd_encoder_weights* w, co
   int rc = sskd::check_launch("embed_ln_kernel");
   if (rc != SSKD_OK) return rc;
 
-  __bf16* x = ws.xa;
-  __bf16* x1 = ws.xb;
+  __bf16* x = ws.xa;  // layer input; the fused MLP writes the layer output over it (row-local, in place)
   for (int li = 0; li < cfg->layers; ++li) {
     const sskd_encoder_layer_weights& lw = w->layers[li];
     SSKD_REQUIRE(lw.wqkv && lw.bqkv && lw.wo && lw.bo && lw.ln1_g && lw.ln1_b && lw.w1 && lw.b1 &&
@@ -1315,7 +1337,7 @@ int run_layers(const sskd_encoder_config* cfg, const sskd_encoder_weights* w, co
     o.gamma = lw.ln1_g;
     o.beta = lw.ln1_b;
     o.eps = cfg->layer_norm_eps;
-    o.out = x1;
+    o.out = nullptr;  // X1 stays in the fused MLP's LDS
     auto qa_kernel = nkt > 8 ? qkv_attention_kernel<true, false>
                              : (d_seg ? qkv_attention_kernel<false, true> : qkv_attention_kernel<false, false>);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(qa_kernel),
@@ -1323,15 +1345,13 @@ int run_layers(const sskd_encoder_config* cfg, const sskd_encoder_weights* w, co
     hipLaunchKernelGGL(qa_kernel, dim3(qa_rows * (NH / qa.hpw)), dim3(512), qa_lds_bytes, st, qa);
     if ((rc = sskd::check_launch("qkv_attention_kernel")) != SSKD_OK) return rc;
 
-    // (Running this GEMM in the attention workgroup's tail - it owns all heads of its 256 tokens -
-    // was built and measured: 5.5 % slower end to end on one box (7.92 vs 7.51 ms).  The step is
-    // bound by the CUs' load / store paths (345 MB per layer at 3.8 TB/s), every workgroup reaches
-    // its tail at the same time, and the tail then runs the same bytes with 1 workgroup per CU.)
-    hipLaunchKernelGGL(gemm_n384_ln_kernel<2>, dim3(Tpad / 128), dim3(512), 0, st, o);
-    if ((rc = sskd::check_launch("gemm_n384_ln_kernel<2>")) != SSKD_OK) return rc;
+    // (Running this GEMM in the attention workgroup's TAIL - it owns all heads of its 256 tokens -
+    // was built and measured: 5.5 % slower end to end on one box (7.92 vs 7.51 ms): every workgroup
+    // reaches its tail at the same time and the tail then runs the same bytes with 1 workgroup per
+    // CU.  It runs as the PROLOGUE of the fused MLP instead: see fused_mlp_ln_kernel.)
 
     MlpParams m{};
-    m.x1 = reinterpret_cast<const bf16x8*>(x1);
+    m.x1 = nullptr;
     m.w1 = static_cast<const bf16x8*>(lw.w1);
     m.b1 = lw.b1;
     m.w2c = static_cast<const bf16x8*>(lw.w2);
@@ -1340,7 +1360,8 @@ int run_layers(const sskd_encoder_config* cfg, const sskd_encoder_weights* w, co
     m.beta = lw.ln2_b;
     m.eps = cfg->layer_norm_eps;
     m.out = x;
-    hipLaunchKernelGGL(fused_mlp_ln_kernel, dim3(Tpad / 128), dim3(512), 0, st, m);
+    m.outp = o;
+    hipLaunchKernelGGL(fused_mlp_ln_kernel<true>, dim3(Tpad / 128), dim3(512), 0, st, m);
     if ((rc = sskd::check_launch("fused_mlp_ln_kernel")) != SSKD_OK) return rc;
   }
   *final_hidden = x;
