@@ -509,21 +509,25 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
     gemm_n384_ln_block<2, true>(p.outp, (int64_t)blockIdx.x * 4, 4, x1img, stats, par, x1img);
     __syncthreads();  // the X1 image is complete
   }
-  bf16x8 x_pro[KSTEPS];  // producers: the B fragments of this wave's token tile
-  if (producer) {
-    const bf16x8* xs = FUSE_OUTPROJ ? x1img + frag_base(tg, 0, KSTEPS) + lane : p.x1 + frag_base(tt, 0, KSTEPS) + lane;
-#pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) x_pro[s] = xs[s * 64];
-  }
-  if constexpr (FUSE_OUTPROJ) __syncthreads();  // everybody has read the image: the buffers are free
-  // W1 chunk 0
-  for (int i = tid; i < WTILE_VEC; i += 512) w1buf[0][i] = p.w1[i];
-  __syncthreads();
-
+  // From here on the two roles never share code: the producers' 96 registers of X1 fragments and the
+  // consumers' 192 accumulators must not be live in one block (the allocator would spill ~90
+  // registers per lane to scratch - 200 MB of extra HBM traffic per layer, measured).  Both branches
+  // execute the same number of workgroup barriers.
+  auto stage_w1_chunk0 = [&]() {
+    if constexpr (FUSE_OUTPROJ) __syncthreads();  // everybody has read the X1 image: the buffers are free
+    for (int i = tid; i < WTILE_VEC; i += 512) w1buf[0][i] = p.w1[i];
+    __syncthreads();
+  };
   // iterations 0 .. MLP_CHUNKS: the producer's burst is real for it < MLP_CHUNKS, the consumer's
   // for it >= 1; edge phases work on stale data whose results nobody reads (branch-free).
   if (producer) {
-    bf16x8 (&x)[KSTEPS] = x_pro;
+    bf16x8 x[KSTEPS];  // the B fragments of this wave's token tile
+    {
+      const bf16x8* xs = FUSE_OUTPROJ ? x1img + frag_base(tg, 0, KSTEPS) + lane : p.x1 + frag_base(tt, 0, KSTEPS) + lane;
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) x[s] = xs[s * 64];
+    }
+    stage_w1_chunk0();
     // ring of PF + 1 registers: the read issued in slot s targets the register consumed in slot
     // s - 1, never the one the MFMA just issued is still reading (WAR stall)
     constexpr int PF = SSKD_MLP_PF, RING = PF + 1;
@@ -607,16 +611,25 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
       SSKD_STAMP(0, it, 3);
       __syncthreads();
     }
-    if constexpr (FUSE_OUTPROJ) {
-      // the weight buffers are dead: X1 goes back to LDS for the consumers' residual
-#pragma unroll
-      for (int s = 0; s < KSTEPS; ++s) x1img[frag_base(tg, s, KSTEPS) + lane] = x[s];
-      __syncthreads();
-    }
   } else {
     f32x16 y[12];
+    if constexpr (FUSE_OUTPROJ) {
+      // Y starts at X1 + b2: the residual is taken from the image NOW, so X1 needs no second home
+      const __bf16* res = reinterpret_cast<const __bf16*>(x1img + frag_base(tg, 0, KSTEPS));
 #pragma unroll
-    for (int nt = 0; nt < 12; ++nt) y[nt] = zero16();
+      for (int nt = 0; nt < 12; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(&par_lds[0][nt * 32 + 8 * g + 4 * h]);
+          const bf16x4 rr = *reinterpret_cast<const bf16x4*>(res + ((2 * nt + (g >> 1)) * 64 + r + 32 * (g & 1)) * 8 + 4 * h);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[nt][4 * g + e] = b[e] + bf2f(rr[e]);
+        }
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < 12; ++nt) y[nt] = zero16();
+    }
+    stage_w1_chunk0();
     constexpr int CR = 5;  // fragment ring of the burst, in output tiles (reads run CR - 1 tiles ahead)
     for (int it = 0; it <= MLP_CHUNKS; ++it) {
       SSKD_STAMP(1, it, 0);
@@ -678,25 +691,33 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
 
     // epilogue: v = y + b2 + residual; LayerNorm over the token's 384 features (192 in this
     // lane, 192 in lane ^ 32)
-    if constexpr (FUSE_OUTPROJ) __syncthreads();  // the producers' X1 write-back
-    const __bf16* res = FUSE_OUTPROJ ? reinterpret_cast<const __bf16*>(x1img + frag_base(tg, 0, KSTEPS))
-                                     : reinterpret_cast<const __bf16*>(p.x1 + frag_base(tt, 0, KSTEPS));
     float sum = 0.f, sq = 0.f;
+    if constexpr (FUSE_OUTPROJ) {
 #pragma unroll
-    for (int nt = 0; nt < 12; ++nt)
+      for (int nt = 0; nt < 12; ++nt)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(&par_lds[0][nt * 32 + 8 * g + 4 * h]);
-        const bf16x4 rr = *reinterpret_cast<const bf16x4*>(
-            res + ((int64_t)((2 * nt + (g >> 1)) * 64 + r + 32 * (g & 1))) * 8 + 4 * h);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v = y[nt][4 * g + e] + b[e] + bf2f(rr[e]);
-          y[nt][4 * g + e] = v;
-          sum += v;
-          sq = fmaf(v, v, sq);
+        for (int i = 0; i < 16; ++i) {
+          sum += y[nt][i];
+          sq = fmaf(y[nt][i], y[nt][i], sq);
         }
-      }
+    } else {
+      const __bf16* res = reinterpret_cast<const __bf16*>(p.x1 + frag_base(tt, 0, KSTEPS));
+#pragma unroll
+      for (int nt = 0; nt < 12; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(&par_lds[0][nt * 32 + 8 * g + 4 * h]);
+          const bf16x4 rr = *reinterpret_cast<const bf16x4*>(
+              res + ((int64_t)((2 * nt + (g >> 1)) * 64 + r + 32 * (g & 1))) * 8 + 4 * h);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = y[nt][4 * g + e] + b[e] + bf2f(rr[e]);
+            y[nt][4 * g + e] = v;
+            sum += v;
+            sq = fmaf(v, v, sq);
+          }
+        }
+    }
     sum = pair_sum(sum);
     sq = pair_sum(sq);
     const float mean = sum * (1.0f / H);

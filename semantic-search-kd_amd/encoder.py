@@ -161,7 +161,9 @@ class Mi355xSentenceEncoder:
         self._workspace: Optional[torch.Tensor] = None
         self._workspace2: Optional[torch.Tensor] = None   # second half of a split batch (side stream)
         self._side_stream: Optional[torch.cuda.Stream] = None
-        self.split_streams = True   # large batches / alternate launches over two HIP streams
+        # large batches / alternate launches over two HIP streams: gave 4 % while the output projection
+        # was a separate load/store-bound kernel; with it fused into the MLP prologue it is neutral (off)
+        self.split_streams = False
         self._staging: List[_Staging] = []
         self._stage_next = 0
         self._rows: list = [None, None]   # per stream lane: (packed ids, segment words)
