@@ -17,6 +17,7 @@
 // The lists of all waves / slices are merged by merge_topk_kernel.
 #include "common.h"
 
+#include <algorithm>
 #include <cfloat>
 #include <cstdlib>
 
@@ -756,11 +757,16 @@ constexpr float SCREEN_EPS_REL = 0.0041f;        // >= 2^-8 (1 + 2^-9) + 3 x 384
 constexpr int SCREEN_FALLBACK_CAP = 1024;        // queries the exact fallback launch is sized for
 constexpr int SCREEN_MAX_CAND = 256;             // candidates re-scored per query (one per thread)
 constexpr int SCREEN_MAX_ENTRIES = 4096;         // list entries of one query staged in LDS
+constexpr int SCREEN_CUS = 256;                  // MI355X: the launch geometry is planned in whole rounds of the chip
 
 // fp32 tiled corpus -> bf16 tiled corpus in A-operand order of v_mfma_f32_32x32x16_bf16:
 // tile t, step s, lane l holds row 32t + (l & 31), columns 16s + 8(l >> 5) + 0..7
+// Also writes the tile's 32 rows ROW-MAJOR in fp32 (rows_rm): the finalize kernel re-scores ~20 scattered
+// rows per query, and in the tiled layout a row is spread over 96 cache lines (16 useful bytes per 128-byte
+// line: 2.6 GB fetched for 0.3 GB used at the bench shape); row-major it is 12 whole lines.
 __global__ __launch_bounds__(256) void make_bf16_tiles_kernel(const float4* __restrict__ tiled, int64_t n_tiles,
-                                                              sbf16x8* __restrict__ out, int* __restrict__ max_norm2) {
+                                                              sbf16x8* __restrict__ out, int* __restrict__ max_norm2,
+                                                              float4* __restrict__ rows_rm) {
   __shared__ float rowss[32];
   const int64_t t = blockIdx.x;
   if (threadIdx.x < 32) rowss[threadIdx.x] = 0.f;
@@ -774,6 +780,9 @@ __global__ __launch_bounds__(256) void make_bf16_tiles_kernel(const float4* __re
     o[0] = (__bf16)a.x; o[1] = (__bf16)a.y; o[2] = (__bf16)a.z; o[3] = (__bf16)a.w;
     o[4] = (__bf16)b.x; o[5] = (__bf16)b.y; o[6] = (__bf16)b.z; o[7] = (__bf16)b.w;
     out[t * BTILE_VEC + v] = o;
+    float4* const dst = rows_rm + (t * TILE_ROWS + r) * (int64_t)(DIM / 4) + 2 * u;  // columns 8u .. 8u + 7
+    dst[0] = a;
+    dst[1] = b;
     atomicAdd(&rowss[r], a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w);
   }
   __syncthreads();
@@ -994,7 +1003,7 @@ struct ScreenFinalParams {
   const float* part_scores;   // [nq][lists][K] screen scores (sorted lists, (-inf, -1) padded)
   const int* part_ids;
   const float* eps2;
-  const float* tiled;         // fp32 tiles: exact re-scoring
+  const float* rows;          // fp32 rows, row-major (the sidecar's copy): exact re-scoring
   const float* queries;
   int K, lists, k, nq;
   int64_t id_offset;
@@ -1111,11 +1120,11 @@ __global__ __launch_bounds__(64) void screen_finalize_kernel(ScreenFinalParams p
     const int idx = c * 64 + lane;
     if (idx < M) {
       const int row = ci[idx];
-      const float4* src = reinterpret_cast<const float4*>(p.tiled) + (int64_t)(row >> 5) * (TILE_ROWS * CHUNKS) + (row & 31);
+      const float4* src = reinterpret_cast<const float4*>(p.rows) + (int64_t)row * (DIM / 4);
       float acc = 0.f;
-#pragma unroll 4
-      for (int u = 0; u < STEPS; ++u) {
-        const float4 a = src[u * 64], b = src[u * 64 + 32];
+#pragma unroll 8
+      for (int u = 0; u < STEPS; ++u) {  // 8 steps = two whole 128-byte lines of the row in flight
+        const float4 a = src[2 * u], b = src[2 * u + 1];
         const float4 qa = *reinterpret_cast<const float4*>(&qv[8 * u]), qb = *reinterpret_cast<const float4*>(&qv[8 * u + 4]);
         acc = fmaf(a.x, qa.x, acc); acc = fmaf(b.x, qb.x, acc);
         acc = fmaf(a.y, qa.y, acc); acc = fmaf(b.y, qb.y, acc);
@@ -1709,7 +1718,7 @@ int sskd_similarity(const float* d_q, int nq, const float* d_d, int nd, int dim,
 
 namespace {
 struct ScreenPlan {
-  int QB, n_qblocks, n_slices, tiles_per_slice, n_tiles, lists_per_query;
+  int QB, LK, n_qblocks, n_slices, tiles_per_slice, n_tiles, lists_per_query;
   size_t part_elems;
 };
 
@@ -1717,28 +1726,50 @@ bool screen_plan(int64_t n_rows, int nq, int k, ScreenPlan* sp) {
   if (k < 1 || k > 10 || nq < 64 || n_rows < 64 * TILE_ROWS) return false;
   ScreenPlan pl{};
   pl.n_tiles = (int)sskd::ceil_div(n_rows, TILE_ROWS);
-  // 128 queries per workgroup cut the corpus re-reads in half; shards small enough to live in L2 /
-  // Infinity Cache do better with twice the workgroups (64 queries each, 2-3 resident per CU)
-  pl.QB = (nq >= 256 && pl.n_tiles >= 8192) ? 4 : 2;
-  pl.n_qblocks = (int)sskd::ceil_div(nq, 32 * pl.QB);
-#ifndef SSKD_SCREEN_TARGET_WGS
-#define SSKD_SCREEN_TARGET_WGS 1024
+  // 128 queries per workgroup (QB = 4) halve the corpus re-reads per MFMA: at 64 queries the tile loads
+  // from L2 take as long as the MFMAs they feed.  Measured on 125 k .. 1 M rows x 10 k queries
+  // (tools/ab_search.py with the FORCE macros below): QB = 4 wins at every size.
+  pl.QB = nq >= 256 ? 4 : 2;
+#ifdef SSKD_SCREEN_FORCE_QB
+  pl.QB = SSKD_SCREEN_FORCE_QB;  // tools/ab_build.py sweeps only
 #endif
-  int slices = (int)sskd::ceil_div(SSKD_SCREEN_TARGET_WGS, pl.n_qblocks);
-  slices = (int)sskd::ceil_div(slices, 8) * 8;
-  const int max_by_lists = SCREEN_MAX_ENTRIES / (SCREEN_LISTK * 2 * SCREEN_WAVES);  // lists = slices * waves * 2
-  if (slices > max_by_lists) slices = max_by_lists / 8 * 8;
-  const int max_slices = (int)sskd::ceil_div(pl.n_tiles, SCREEN_WAVES);
-  if (slices > max_slices) slices = max_slices;
-  // a wave needs a few dozen tiles to amortise filling its lists and warming the pools: on small
-  // shards (the 8-GPU shard of cfg 2 is 125 k rows) fewer, longer slices win (2.46 -> 2.12 ms)
-  while (slices > 8 && pl.n_tiles / (slices * SCREEN_WAVES) < 48) slices -= 8;
-  if (slices < 1) slices = 1;
+  pl.n_qblocks = (int)sskd::ceil_div(nq, 32 * pl.QB);
+  // Slices: every slice starts its lists and pruning pools cold, which costs ~0.09 ms per slice at
+  // 10 k queries whatever the corpus size (3 -> 6 slices: +0.25 ms at 125 k rows and at 1 M), while a
+  // launch that does not fill whole rounds of the chip's 256 CUs (one 8-wave workgroup per CU: 99 KB of
+  // LDS at QB = 4, 144-152 VGPRs at QB = 2) wastes the idle share of the matrix time.  Pick the round count that minimises
+  //   matrix_time / utilisation + 0.09 ms x slices.
+  // 10 k queries: 79 query blocks x 3 slices = 237 workgroups in ONE round (125 k rows: 2.16 -> 1.76 ms,
+  // 1 M rows: 9.34 -> 9.16 ms against the former 16 slices in five rounds).
+  const int resident = SCREEN_CUS;
+  const int max_slices = std::max(1, (int)sskd::ceil_div(pl.n_tiles, SCREEN_WAVES));
+  const double matrix_ms = (double)n_rows * nq * (2.0 * DIM) / 1.0e12;   // at ~1 PFLOP/s sustained
+  const double warm_ms = 0.09 * nq / 10000.0;
+  int slices = 1;
+  double best = 1e300;
+  for (int rounds = 1; rounds <= 8; ++rounds) {
+    int sl = std::min(std::max(1, rounds * resident / pl.n_qblocks), max_slices);
+    const int wgs = sl * pl.n_qblocks;
+    const double util = (double)wgs / ((double)resident * sskd::ceil_div(wgs, resident));
+    const double cost = matrix_ms / util + warm_ms * sl;
+    if (cost < best - 1e-9) { best = cost; slices = sl; }
+  }
+  // few, long lists hold more of a query's candidate band each: deeper lists keep the "list full inside
+  // the band" fallback (an exact scan of the whole shard for a handful of queries) out of the common path
+  pl.LK = slices * SCREEN_WAVES * 2 < 128 ? 8 : 6;
+#ifdef SSKD_SCREEN_FORCE_LK
+  pl.LK = SSKD_SCREEN_FORCE_LK;
+#endif
+  const int max_by_lists = SCREEN_MAX_ENTRIES / (pl.LK * 2 * SCREEN_WAVES);  // lists = slices * waves * 2
+  if (slices > max_by_lists) slices = max_by_lists;
+#ifdef SSKD_SCREEN_FORCE_SLICES
+  slices = SSKD_SCREEN_FORCE_SLICES;
+#endif
   pl.tiles_per_slice = (int)sskd::ceil_div(pl.n_tiles, slices);
   pl.n_slices = (int)sskd::ceil_div(pl.n_tiles, pl.tiles_per_slice);
   pl.lists_per_query = pl.n_slices * SCREEN_WAVES * 2;
-  if (pl.lists_per_query * SCREEN_LISTK > SCREEN_MAX_ENTRIES) return false;
-  pl.part_elems = (size_t)nq * pl.lists_per_query * SCREEN_LISTK;
+  if (pl.lists_per_query * pl.LK > SCREEN_MAX_ENTRIES) return false;
+  pl.part_elems = (size_t)nq * pl.lists_per_query * pl.LK;
   *sp = pl;
   return true;
 }
@@ -1782,9 +1813,13 @@ ScreenWs screen_carve(void* base, const ScreenPlan& pl, int64_t n_rows, int nq, 
 }
 }  // namespace
 
+// screening sidecar: [bf16 tiles][256 B: max |row|^2][fp32 rows, row-major (re-scoring gathers)]
+static inline size_t sidecar_norm_offset(int64_t n_rows) { return (size_t)sskd::ceil_div(n_rows, TILE_ROWS) * BTILE_VEC * 16; }
+static inline size_t sidecar_rows_offset(int64_t n_rows) { return sidecar_norm_offset(n_rows) + 256; }
+
 size_t sskd_index_bf16_bytes(int64_t n_rows) {
   if (n_rows <= 0) return 0;
-  return (size_t)sskd_index_padded_rows(n_rows) * DIM * 2 + 256;  // tiles + { max |row|^2 }
+  return sidecar_rows_offset(n_rows) + (size_t)sskd_index_padded_rows(n_rows) * DIM * sizeof(float);
 }
 
 int sskd_index_make_bf16(const float* d_tiled, int64_t n_rows, void* d_bf16, void* stream) {
@@ -1793,10 +1828,11 @@ int sskd_index_make_bf16(const float* d_tiled, int64_t n_rows, void* d_bf16, voi
   SSKD_REQUIRE(d_tiled && d_bf16, "index_make_bf16: null pointer");
   hipStream_t st = sskd::as_stream(stream);
   const int64_t tiles = sskd::ceil_div(n_rows, TILE_ROWS);
-  int* max_norm2 = reinterpret_cast<int*>(static_cast<char*>(d_bf16) + (size_t)tiles * BTILE_VEC * 16);
+  int* max_norm2 = reinterpret_cast<int*>(static_cast<char*>(d_bf16) + sidecar_norm_offset(n_rows));
+  float4* rows_rm = reinterpret_cast<float4*>(static_cast<char*>(d_bf16) + sidecar_rows_offset(n_rows));
   if (hipMemsetAsync(max_norm2, 0, 256, st) != hipSuccess) return sskd::fail(SSKD_ERR_HIP, "index_make_bf16: memset failed");
   hipLaunchKernelGGL(make_bf16_tiles_kernel, dim3((unsigned)tiles), dim3(256), 0, st,
-                     reinterpret_cast<const float4*>(d_tiled), tiles, static_cast<sbf16x8*>(d_bf16), max_norm2);
+                     reinterpret_cast<const float4*>(d_tiled), tiles, static_cast<sbf16x8*>(d_bf16), max_norm2, rows_rm);
   return sskd::check_launch("make_bf16_tiles_kernel");
 }
 
@@ -1834,7 +1870,7 @@ int sskd_index_search_screened(const float* d_tiled, const void* d_bf16, int64_t
   hipStream_t st = sskd::as_stream(stream);
   const ScreenWs w = screen_carve(d_workspace, pl, n_rows, nq, k);
   const int64_t tiles = sskd::ceil_div(n_rows, TILE_ROWS);
-  const int* max_norm2 = reinterpret_cast<const int*>(static_cast<const char*>(d_bf16) + (size_t)tiles * BTILE_VEC * 16);
+  const int* max_norm2 = reinterpret_cast<const int*>(static_cast<const char*>(d_bf16) + sidecar_norm_offset(n_rows));
 
   hipLaunchKernelGGL(fill_int_kernel, dim3((unsigned)sskd::ceil_div(nq * 11, 256)), dim3(256), 0, st, w.tau, nq * 11,
                      (int)0x80000000);
@@ -1858,14 +1894,17 @@ int sskd_index_search_screened(const float* d_tiled, const void* d_bf16, int64_t
   sp.lists_per_query = pl.lists_per_query;
   const size_t lds = (size_t)pl.QB * BSTEPS * 64 * 16 + (size_t)pl.QB * 32 * 11 * sizeof(int);
   if (ev_scan_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_scan_begin), st);
-  if (pl.QB == 4) {
-    auto kern = screen_topk_kernel<10, 4, SCREEN_WAVES>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(pl.n_qblocks * pl.n_slices), dim3(SCREEN_WAVES * 64), lds, st, sp);
-  } else {
-    auto kern = screen_topk_kernel<10, 2, SCREEN_WAVES>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(pl.n_qblocks * pl.n_slices), dim3(SCREEN_WAVES * 64), lds, st, sp);
+  const void* kern = nullptr;
+  if (pl.QB == 4 && pl.LK == 8) kern = reinterpret_cast<const void*>(screen_topk_kernel<10, 4, SCREEN_WAVES, 8>);
+  else if (pl.QB == 4 && pl.LK == 6) kern = reinterpret_cast<const void*>(screen_topk_kernel<10, 4, SCREEN_WAVES, 6>);
+  else if (pl.QB == 2 && pl.LK == 8) kern = reinterpret_cast<const void*>(screen_topk_kernel<10, 2, SCREEN_WAVES, 8>);
+  else if (pl.QB == 2 && pl.LK == 6) kern = reinterpret_cast<const void*>(screen_topk_kernel<10, 2, SCREEN_WAVES, 6>);
+  else return sskd::fail(SSKD_ERR_UNSUPPORTED, "index_search_screened: no screening kernel for QB=%d LK=%d", pl.QB, pl.LK);
+  (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  {
+    void* args[] = {&sp};
+    if (hipLaunchKernel(kern, dim3(pl.n_qblocks * pl.n_slices), dim3(SCREEN_WAVES * 64), args, lds, st) != hipSuccess)
+      return sskd::fail(SSKD_ERR_HIP, "index_search_screened: screening launch failed");
   }
   if (ev_scan_end) (void)hipEventRecord(static_cast<hipEvent_t>(ev_scan_end), st);
   int rc = sskd::check_launch("screen_topk_kernel");
@@ -1875,9 +1914,9 @@ int sskd_index_search_screened(const float* d_tiled, const void* d_bf16, int64_t
   fp.part_scores = w.part_scores;
   fp.part_ids = w.part_ids;
   fp.eps2 = w.eps2;
-  fp.tiled = d_tiled;
+  fp.rows = reinterpret_cast<const float*>(static_cast<const char*>(d_bf16) + sidecar_rows_offset(n_rows));
   fp.queries = d_queries;
-  fp.K = SCREEN_LISTK;
+  fp.K = pl.LK;
   fp.lists = pl.lists_per_query;
   fp.k = k;
   fp.nq = nq;
@@ -1888,7 +1927,7 @@ int sskd_index_search_screened(const float* d_tiled, const void* d_bf16, int64_t
   fp.fb_qid = w.fb_qid;
   fp.fb_queries = w.fb_queries;
   fp.status = d_status;
-  const size_t fin_lds = ((size_t)2 * pl.lists_per_query * SCREEN_LISTK + DIM + SCREEN_MAX_CAND) * sizeof(float);
+  const size_t fin_lds = ((size_t)2 * pl.lists_per_query * pl.LK + DIM + SCREEN_MAX_CAND) * sizeof(float);
   hipLaunchKernelGGL(screen_finalize_kernel, dim3(nq), dim3(64), fin_lds, st, fp);
   if ((rc = sskd::check_launch("screen_finalize_kernel")) != SSKD_OK) return rc;
 
