@@ -323,30 +323,54 @@ __device__ inline void gemm_n384_ln_block(const GemmN384Params& p, int64_t tt0, 
   bf16x8 stage[6];
   bf16x8* const lds_flat0 = wl;
   bf16x8* const lds_flat1 = wl + 4 * HTILE_VEC;
+  // The block is latency-bound (a workgroup's MFMAs take ~4 us, the block ~12): every global load is
+  // requested one step before the step that needs it - the first activation chunk together with the
+  // first weight tiles, chunk kc + 1 during the last tile pair of chunk kc, the residual rows during
+  // the last tile pair of all.
+  const bf16x8* xs = p.x + frag_base(tt, 0, KTOT) + lane;
+  bf16x8 x[KC2][KS2];
+#pragma unroll
+  for (int s = 0; s < KS2; ++s) x[0][s] = xs[s * 64];
 #pragma unroll
   for (int i = 0; i < 6; ++i) lds_flat0[tid + 512 * i] = *stage_src(0, tid + 512 * i);
   __syncthreads();
 
-  const bf16x8* xs = p.x + frag_base(tt, 0, KTOT) + lane;
+  const __bf16* res = p.resid + frag_base(tt, 0, KSTEPS) * 8;
+  bf16x4 rr[6][4];
 #pragma unroll
   for (int kc = 0; kc < KC2; ++kc) {
-    // compiler-only barrier: keep this chunk's activation loads below the previous chunk's MFMAs
-    // (requesting every chunk up front only added spills: measured no faster)
-    asm volatile("" ::: "memory");
-    bf16x8 x[KS2];
-#pragma unroll
-    for (int s = 0; s < KS2; ++s) x[s] = xs[(KS2 * kc + s) * 64];
 #pragma unroll
     for (int jp = 0; jp < 3; ++jp) {
       const int it = kc * 3 + jp;
       const int cur = it & 1;
       const bool more = it + 1 < NIT;
+      asm volatile("" ::: "memory");  // compiler-only: keep each step's requests where they are written
       if (more) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) stage[i] = *stage_src(it + 1, tid + 512 * i);
+#ifdef SSKD_PRO_XNEXT_EARLY
+        if (jp == 2) {
+#pragma unroll
+          for (int s = 0; s < KS2; ++s) x[(kc + 1) % KC2][s] = xs[(KS2 * (kc + 1) + s) * 64];
+        }
+#endif
+      } else {
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            rr[j][g] = *reinterpret_cast<const bf16x4*>(
+                res + ((int64_t)((2 * (nh * 6 + j) + (g >> 1)) * 64 + r + 32 * (g & 1))) * 8 + 4 * h);
       }
-      acc[2 * jp] = tile_mfma<KS2, 4>(wtile(cur, nh, 0) + lane, x, acc[2 * jp]);
-      acc[2 * jp + 1] = tile_mfma<KS2, 4>(wtile(cur, nh, 1) + lane, x, acc[2 * jp + 1]);
+      asm volatile("" ::: "memory");
+#ifndef SSKD_PRO_XNEXT_EARLY
+      if (jp == 0 && kc > 0) {
+#pragma unroll
+        for (int s = 0; s < KS2; ++s) x[kc][s] = xs[(KS2 * kc + s) * 64];
+      }
+#endif
+      acc[2 * jp] = tile_mfma<KS2, 4>(wtile(cur, nh, 0) + lane, x[kc], acc[2 * jp]);
+      acc[2 * jp + 1] = tile_mfma<KS2, 4>(wtile(cur, nh, 1) + lane, x[kc], acc[2 * jp + 1]);
       if (more) {
         bf16x8* dst = cur ? lds_flat0 : lds_flat1;
 #pragma unroll
@@ -358,8 +382,6 @@ __device__ inline void gemm_n384_ln_block(const GemmN384Params& p, int64_t tt0, 
 
   // epilogue: v = acc + bias + residual; LayerNorm over the token's 384 features, of which
   // this lane holds 96, lane ^ 32 another 96 and the partner wave (other nh) the remaining 192
-  asm volatile("" ::: "memory");
-  const __bf16* res = p.resid + frag_base(tt, 0, KSTEPS) * 8;
   float sum = 0.f, sq = 0.f;
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
@@ -367,11 +389,9 @@ __device__ inline void gemm_n384_ln_block(const GemmN384Params& p, int64_t tt0, 
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const f32x4 b = *reinterpret_cast<const f32x4*>(&par[nt * 32 + 8 * g + 4 * h]);
-      const bf16x4 rr = *reinterpret_cast<const bf16x4*>(
-          res + ((int64_t)((2 * nt + (g >> 1)) * 64 + r + 32 * (g & 1))) * 8 + 4 * h);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float v = acc[j][4 * g + e] + b[e] + bf2f(rr[e]);
+        const float v = acc[j][4 * g + e] + b[e] + bf2f(rr[j][g][e]);
         acc[j][4 * g + e] = v;
         sum += v;
         sq = fmaf(v, v, sq);

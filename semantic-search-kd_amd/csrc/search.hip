@@ -865,8 +865,19 @@ __global__ __launch_bounds__(WAVES * 64) void screen_topk_kernel(ScreenParams p)
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, h = lane >> 5;
+#ifdef SSKD_SCREEN_NO_XCD_MAP
   const int slice = blockIdx.x % p.n_slices;
   const int qblk = blockIdx.x / p.n_slices;
+#else
+  // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8) and each XCD has its own L2: give XCD x
+  // a CONTIGUOUS range of (slice, query block) pairs, slice-major, so that a slice's tiles are pulled
+  // through one or two L2s instead of all eight.
+  const int n_qblocks = gridDim.x / p.n_slices;
+  const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+  const int logical = xcd * (gridDim.x >> 3) + min(xcd, (int)(gridDim.x & 7)) + within;
+  const int slice = logical / n_qblocks;
+  const int qblk = logical % n_qblocks;
+#endif
   const int q0 = qblk * (32 * QB);
 
   for (int idx = tid; idx < QB * BSTEPS * 64; idx += WAVES * 64) {

@@ -12,7 +12,7 @@ sys.path.insert(0, str(REPO))
 from semantic_search_kd_amd import _native  # noqa: E402
 
 import os
-N, NQ, K = int(os.environ.get('AB_ROWS', 1_000_000)), 10_000, 10
+N, NQ, K = int(os.environ.get('AB_ROWS', 1_000_000)), int(os.environ.get('AB_NQ', 10_000)), 10
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(1)
 corpus = torch.nn.functional.normalize(torch.randn((N, 384), generator=g, device=dev), dim=1)
