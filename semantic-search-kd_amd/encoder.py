@@ -161,6 +161,7 @@ class Mi355xSentenceEncoder:
         self._workspace: Optional[torch.Tensor] = None
         self._workspace2: Optional[torch.Tensor] = None   # second half of a split batch (side stream)
         self._side_stream: Optional[torch.cuda.Stream] = None
+        self._copy_stream: Optional[torch.cuda.Stream] = None
         # large batches / alternate launches over two HIP streams: gave 4 % while the output projection
         # was a separate load/store-bound kernel; with it fused into the MLP prologue it is neutral (off)
         self.split_streams = False
@@ -497,6 +498,10 @@ class Mi355xSentenceEncoder:
         texts = [sentences] if single else list(sentences)
         n = len(texts)
         out = torch.empty((n, self.config.hidden_size), dtype=torch.float32, device=self.device)
+        # NumPy out: every chunk's rows start their way to pinned host memory as soon as the chunk is
+        # enqueued, so the device-to-host copy hides behind the next chunk's forward
+        to_host = convert_to_numpy or not convert_to_tensor
+        host = torch.empty((n, self.config.hidden_size), dtype=torch.float32, pin_memory=True) if (to_host and n) else None
         real = padded = 0.0
         if n:
             if self._tok_pool is None:
@@ -514,6 +519,8 @@ class Mi355xSentenceEncoder:
                         self.encode_ragged(flat, lengths, normalize=True, out=out[lo : bounds[ci + 1]])
                         real += self.last_encode_stats["real_tokens"]
                         padded += self.last_encode_stats["padded_tokens"]
+                        if host is not None:
+                            self._rows_to_host(out, host, lo, bounds[ci + 1])
                         continue
                     cu = np.zeros(len(lengths) + 1, np.int64)
                     np.cumsum(lengths, out=cu[1:])
@@ -535,12 +542,28 @@ class Mi355xSentenceEncoder:
                         out[torch.from_numpy(lo + idx).to(self.device)] = self.encode_token_ids(ids, mask, normalize=True)
                         real += float(lengths[idx].sum())
                         padded += float(idx.size * (-(-width // 32) * 32))
+                    if host is not None:
+                        self._rows_to_host(out, host, lo, bounds[ci + 1])
         self.last_encode_stats = {"real_tokens": real, "padded_tokens": padded,
                                   "padding_overhead": (padded / real - 1.0) if real else 0.0}
-        if convert_to_tensor and not convert_to_numpy:
+        if not to_host:
             return out[0] if single else out
-        arr = out.cpu().numpy()
+        if host is None:
+            arr = np.empty((0, self.config.hidden_size), np.float32)
+        else:
+            self._copy_stream.synchronize()
+            arr = host.numpy()   # a view of the pinned block: no second copy; freed with the array
         return arr[0] if single else arr
+
+    def _rows_to_host(self, out: torch.Tensor, host: torch.Tensor, lo: int, hi: int) -> None:
+        """Start the device-to-host copy of finished rows on a copy stream of its own (ordered after the
+        work enqueued so far), so the next chunk's kernels do not queue behind it."""
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(self.device)
+        self._copy_stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self._copy_stream):
+            host[lo:hi].copy_(out[lo:hi], non_blocking=True)
+        out.record_stream(self._copy_stream)
 
     def cleanup(self) -> None:
         self._workspace = None
