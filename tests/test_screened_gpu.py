@@ -5,6 +5,8 @@ same gate as tests/test_search_gpu.py; on top, the fallback machinery is forced:
 corpora (a per-lane list full inside the candidate band -> exact fallback inside the call) and more
 unproven queries than the fallback holds (status flag -> the host path re-runs the exact scan).
 """
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -150,3 +152,57 @@ def test_screened_equals_exact_scan_at_full_size(gpu, native_lib, n, nq):
     assert index.last_status is None
     assert torch.equal(i1, i2) and torch.equal(s1, s2)
     assert int(i1.min()) >= 11 and (torch.diff(s1, dim=1) <= 0).all()
+
+
+def _exact(lib, tiled, n, q, nq, k, id_offset):
+    out_s = torch.empty((nq, k), device="cuda")
+    out_i = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    ws = torch.empty(int(lib.sskd_index_search_workspace_bytes(n, nq, k)), dtype=torch.uint8, device="cuda")
+    _native.check(lib.sskd_index_search(tiled.data_ptr(), n, q.data_ptr(), nq, k, id_offset, out_s.data_ptr(),
+                                        out_i.data_ptr(), ws.data_ptr(), ws.numel(), stream()))
+    return out_s, out_i
+
+
+def test_screened_equals_exact_scan_over_random_launch_geometries(gpu, native_lib):
+    """The launch plan (queries per workgroup, slices, list depth, XCD mapping) is a function of the shape:
+    sweep shapes across its regimes - one slice, slices capped by the tile count, query blocks with a
+    ragged tail, 6- and 8-deep lists - and demand the exact scan's bits (that scan is oracle-pinned in
+    tests/test_search_gpu.py).  Clustered rows keep the candidate bands busy."""
+    lib = native_lib
+    rng = np.random.default_rng(20260)
+    shapes = [(2048, 64), (2100, 256), (2050, 1000), (4000, 10000), (33000, 255), (33000, 256), (70001, 2999),
+              (250000, 4100), (9000, 513), (640000, 700)]
+    for _ in range(6):
+        shapes.append((int(rng.integers(2048, 300000)), int(rng.integers(64, 6000))))
+    g = torch.Generator(device="cuda").manual_seed(77)
+    seen = set()
+    for n, nq in shapes:
+        k = int(rng.integers(1, 11))
+        id_offset = int(rng.integers(0, 1 << 40))
+        centres = torch.randn((64, 384), generator=g, device="cuda")
+        corpus = torch.nn.functional.normalize(
+            centres[torch.randint(0, 64, (n,), generator=g, device="cuda")] * 0.35
+            + torch.randn((n, 384), generator=g, device="cuda"), dim=1)
+        queries = torch.nn.functional.normalize(
+            corpus[torch.randint(0, n, (nq,), generator=g, device="cuda")] * 0.5
+            + torch.randn((nq, 384), generator=g, device="cuda"), dim=1)
+        qpb, passes, slices = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _native.check(lib.sskd_index_search_screened_plan(n, nq, k, ctypes.byref(qpb), ctypes.byref(passes),
+                                                          ctypes.byref(slices)))
+        seen.add((qpb.value, slices.value * 16 < 128))
+        tiled = torch.zeros(int(lib.sskd_index_tiled_bytes(n)) // 4, dtype=torch.float32, device="cuda")
+        _native.check(lib.sskd_index_add_rows(corpus.data_ptr(), n, 0, tiled.data_ptr(), 0, stream()))
+        bf = torch.empty(int(lib.sskd_index_bf16_bytes(n)), dtype=torch.uint8, device="cuda")
+        _native.check(lib.sskd_index_make_bf16(tiled.data_ptr(), n, bf.data_ptr(), stream()))
+        out_s = torch.full((nq, k), float("nan"), device="cuda")
+        out_i = torch.full((nq, k), -7, dtype=torch.int64, device="cuda")
+        status = torch.full((2,), -1, dtype=torch.int32, device="cuda")
+        ws = torch.empty(int(lib.sskd_index_search_screened_workspace_bytes(n, nq, k)), dtype=torch.uint8, device="cuda")
+        _native.check(lib.sskd_index_search_screened(tiled.data_ptr(), bf.data_ptr(), n, queries.data_ptr(), nq, k, id_offset,
+                                                     out_s.data_ptr(), out_i.data_ptr(), status.data_ptr(), ws.data_ptr(),
+                                                     ws.numel(), stream(), None, None))
+        ref_s, ref_i = _exact(lib, tiled, n, queries, nq, k, id_offset)
+        torch.cuda.synchronize()
+        assert int(status[0]) == 0, (n, nq, k)
+        assert torch.equal(out_i, ref_i) and torch.equal(out_s, ref_s), (n, nq, k, int(status[1]))
+    assert {q for q, _ in seen} == {64, 128} and {d for _, d in seen} == {True, False}, seen
