@@ -25,6 +25,7 @@ struct GemmArgs {
   int accumulate;      // fp32 output only: C += result
   int split_k;         // > 1 (unbatched, fp32 accumulate only): K is cut into split_k slices, one workgroup
                        // layer each, partial products meet through fp32 atomics (order not reproducible)
+  int act;             // bf16 output only: 0 = none, 1 = erf-GELU applied to (alpha * acc + bias) in the epilogue
 };
 
 int launch_gemm_nt(const GemmArgs& a, hipStream_t st);
@@ -46,6 +47,13 @@ int launch_add_ln_fwd(const bf16_t* a, const bf16_t* b, const float* gamma, cons
 // dz = LN backward of dy; dgamma / dbeta (fp32 [H]) are ACCUMULATED (atomics).
 int launch_ln_bwd(const bf16_t* dy, const bf16_t* z, const float* mean, const float* rstd, const float* gamma,
                   int64_t M, int H, bf16_t* dz, float* dgamma, float* dbeta, hipStream_t st);
+
+// Inference attention, fused (no score matrix in memory): for every (batch row, head)
+//   ctx[b, :, h*DH : (h+1)*DH] = softmax(scale * Q K^T + (key masked ? -inf : 0)) V
+// with Q / K / V the column blocks [0, H) / [H, 2H) / [2H, 3H) of the row-major qkv [B*S, 3H].
+// DH in {32, 64, 128}; S a multiple of 32, at most 512.
+int launch_attention_fwd(const bf16_t* qkv, const int32_t* key_mask, int B, int S, int heads, int DH, float scale,
+                         bf16_t* ctx, hipStream_t st);
 
 // rows of S scores (bf16, in place): P = softmax(scale * s + (key masked ? -inf : 0)).
 int launch_softmax_fwd(bf16_t* scores, const int32_t* key_mask, int B, int heads, int S, float scale, hipStream_t st);

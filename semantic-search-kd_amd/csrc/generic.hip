@@ -122,7 +122,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
         for (int g = 0; g < 4; ++g)
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            Ct[(wm * 64 + i * 32 + 8 * g + 4 * h + e) * LDC + nl] = (bf16_t)(p.alpha * acc[i][j][4 * g + e] + bias);
+          {
+            float v = p.alpha * acc[i][j][4 * g + e] + bias;
+            if (p.act == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+            Ct[(wm * 64 + i * 32 + 8 * g + 4 * h + e) * LDC + nl] = (bf16_t)v;
+          }
       }
     __syncthreads();
     bf16_t* Cg = reinterpret_cast<bf16_t*>(Cb) + cbase;
@@ -164,6 +168,152 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
             reinterpret_cast<bf16_t*>(Cb)[off] = (bf16_t)v;
           }
         }
+    }
+}
+
+// ------------------------------------------------------------------------- //
+// Fused inference attention (teacher cross-encoder): one workgroup = one (batch row, head) and up to 8
+// query tiles of 32 (one per wave); K and V of the head are staged once in LDS in MFMA fragment order.
+//   S^T = K Q^T      A = K fragments [key, dim] (16 contiguous bytes of a qkv row), B = Q^T fragments
+//                    (registers, 16 contiguous bytes of a qkv row): accumulators [key, query], the
+//                    QUERY on the lane, so the online softmax is lane-local (+ one exchange with lane ^ 32)
+//   O^T = V^T P^T    B = P^T: the score accumulators, exponentiated and packed, ARE the B operand
+//                    (k index 8h + e' <-> key 16 s2 + 8 (e' >> 2) + 4h + (e' & 3)); A = V^T fragments
+//                    [dim, key] in that same key order - V is transposed into it while being staged.
+// Same operand trick as the hidden-384 inference kernel (encoder.hip), with operands from memory.
+// ------------------------------------------------------------------------- //
+constexpr float ATT_NEG = -1.0e30f;
+
+struct AttnArgs {
+  const bf16_t* qkv;
+  const int32_t* mask;
+  bf16_t* ctx;
+  int B, S, NH, H;
+  int nkt;      // S / 32
+  int qsplit;   // workgroups per (row, head): ceil(nkt / 8)
+  float scale2; // scale * log2(e)
+};
+
+__device__ inline float pair_max32(float v) { return fmaxf(v, __shfl_xor(v, 32)); }
+__device__ inline float pair_sum32(float v) { return v + __shfl_xor(v, 32); }
+
+template <int DH>
+__global__ __launch_bounds__(512) void attention_fwd_kernel(AttnArgs p) {
+  constexpr int KS = DH / 16;   // k-steps of a score tile
+  constexpr int DT = DH / 32;   // 32-wide tiles of the head dimension
+  extern __shared__ __attribute__((aligned(16))) unsigned char att_lds[];
+  bf16x8* const kl = reinterpret_cast<bf16x8*>(att_lds);                        // [nkt][KS][64]
+  bf16_t* const vl = reinterpret_cast<bf16_t*>(kl + (size_t)p.nkt * KS * 64);   // [nkt][DT][2][64][8]
+  float* const mb = reinterpret_cast<float*>(vl + (size_t)p.S * DH);            // [S] additive key bias
+  __shared__ int s_kmax;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int qs = blockIdx.x % p.qsplit;
+  const int bh = blockIdx.x / p.qsplit;
+  const int head = bh % p.NH, b = bh / p.NH;
+  const int64_t row0 = (int64_t)b * p.S;
+  const int64_t ld = 3 * (int64_t)p.H;
+  const bf16_t* base = p.qkv + row0 * ld + (int64_t)head * DH;
+
+  if (tid == 0) s_kmax = 0;
+  __syncthreads();
+  for (int i = tid; i < p.S; i += 512) {
+    const bool on = p.mask[row0 + i] != 0;
+    mb[i] = on ? 0.f : ATT_NEG;
+    if (on) atomicMax(&s_kmax, i / 32 + 1);
+  }
+  // K: 16-byte pieces straight into fragment order
+  constexpr int CPK = DH / 8;  // 8-element chunks per key
+  for (int v = tid; v < p.S * CPK; v += 512) {
+    const int key = v / CPK, c = v - key * CPK;
+    const bf16x8 kv = *reinterpret_cast<const bf16x8*>(base + (int64_t)key * ld + p.H + 8 * c);
+    kl[((key >> 5) * KS + (c >> 1)) * 64 + (key & 31) + 32 * (c & 1)] = kv;
+    // V: the same piece of the V block, scattered transposed into the P^T key order
+    const bf16x8 vv = *reinterpret_cast<const bf16x8*>(base + (int64_t)key * ld + 2 * p.H + 8 * c);
+    const int kk = key & 31, g = kk >> 3, hh = (kk >> 2) & 1, e = kk & 3;
+    const int s2 = g >> 1, ep = 4 * (g & 1) + e;
+#pragma unroll
+    for (int e8 = 0; e8 < 8; ++e8) {
+      const int d = 8 * c + e8;
+      vl[(((((key >> 5) * DT + (d >> 5)) * 2 + s2) * 64) + (d & 31) + 32 * hh) * 8 + ep] = vv[e8];
+    }
+  }
+  const int qt = qs * 8 + wave;
+  const bool active = qt < p.nkt;
+  bf16x8 qf[KS];
+  {
+    const bf16_t* qrow = base + (int64_t)((active ? qt : 0) * 32 + j) * ld + 8 * h;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qrow + 16 * s);
+  }
+  __syncthreads();
+  if (!active) return;
+  const int kmax = s_kmax;
+
+  f32x16 o[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
+  float m = ATT_NEG, l = 0.f;
+  const bf16x8* vfr = reinterpret_cast<const bf16x8*>(vl);
+  for (int kt = 0; kt < kmax; ++kt) {
+    f32x16 sc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sc[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl[(kt * KS + s) * 64 + lane], qf[s], sc, 0, 0, 0);
+    // sc[4g + e] = score(key 32 kt + 8g + 4h + e, query = lane & 31)
+    float mt = ATT_NEG;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 bias = *reinterpret_cast<const float4*>(&mb[kt * 32 + 8 * g + 4 * h]);
+      sc[4 * g + 0] = fmaf(sc[4 * g + 0], p.scale2, bias.x);
+      sc[4 * g + 1] = fmaf(sc[4 * g + 1], p.scale2, bias.y);
+      sc[4 * g + 2] = fmaf(sc[4 * g + 2], p.scale2, bias.z);
+      sc[4 * g + 3] = fmaf(sc[4 * g + 3], p.scale2, bias.w);
+      mt = fmaxf(fmaxf(fmaxf(mt, sc[4 * g + 0]), fmaxf(sc[4 * g + 1], sc[4 * g + 2])), sc[4 * g + 3]);
+    }
+    mt = pair_max32(mt);
+    if (__any(mt > m)) {
+      const float m_new = fmaxf(m, mt);
+      const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+      l *= alpha;
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[t][i] *= alpha;
+      m = m_new;
+    }
+    bf16x8 pf[2];
+    float ps = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float e = __builtin_amdgcn_exp2f(sc[i] - m);
+      ps += e;
+      pf[i >> 3][i & 7] = (bf16_t)e;
+    }
+    l += ps;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[((kt * DT + t) * 2 + 0) * 64 + lane], pf[0], o[t], 0, 0, 0);
+      o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[((kt * DT + t) * 2 + 1) * 64 + lane], pf[1], o[t], 0, 0, 0);
+    }
+  }
+  l = pair_sum32(l);
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  // o[t][4g + e] = O[query = lane & 31][dim 32t + 8g + 4h + e]: 4 consecutive dims = one 8-byte store
+  bf16_t* out = p.ctx + (row0 + qt * 32 + j) * (int64_t)p.H + (int64_t)head * DH;
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      bf16x4 w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = (bf16_t)(o[t][4 * g + e] * inv);
+      *reinterpret_cast<bf16x4*>(out + 32 * t + 8 * g + 4 * h) = w;
     }
 }
 
@@ -653,6 +803,35 @@ int launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
   if (a.K % 64 == 0) hipLaunchKernelGGL(gemm_nt_kernel<64>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(gemm_nt_kernel<32>, grid, dim3(256), 0, st, a);
   return sskd::check_launch("gemm_nt_kernel");
+}
+
+int launch_attention_fwd(const bf16_t* qkv, const int32_t* key_mask, int B, int S, int heads, int DH, float scale,
+                         bf16_t* ctx, hipStream_t st) {
+  if (B == 0) return SSKD_OK;
+  SSKD_REQUIRE(qkv && key_mask && ctx, "attention_fwd: null pointer");
+  SSKD_REQUIRE(S >= 32 && S % 32 == 0 && S <= 512, "attention_fwd: S=%d must be a multiple of 32 in [32, 512]", S);
+  SSKD_REQUIRE(DH == 32 || DH == 64 || DH == 128, "attention_fwd: head width %d not in {32, 64, 128}", DH);
+  AttnArgs a{};
+  a.qkv = qkv;
+  a.mask = key_mask;
+  a.ctx = ctx;
+  a.B = B;
+  a.S = S;
+  a.NH = heads;
+  a.H = heads * DH;
+  a.nkt = S / 32;
+  a.qsplit = (a.nkt + 7) / 8;
+  a.scale2 = scale * 1.4426950408889634f;
+  const size_t lds = (size_t)S * DH * 2 * 2 + (size_t)S * sizeof(float);
+  const dim3 grid((unsigned)(B * heads * a.qsplit));
+  auto go = [&](auto kern) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a);
+  };
+  if (DH == 32) go(attention_fwd_kernel<32>);
+  else if (DH == 64) go(attention_fwd_kernel<64>);
+  else go(attention_fwd_kernel<128>);
+  return sskd::check_launch("attention_fwd_kernel");
 }
 
 int launch_transpose(const TransposeArgs& a, hipStream_t st) {

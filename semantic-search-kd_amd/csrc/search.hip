@@ -1906,6 +1906,11 @@ int sskd_index_search_screened(const float* d_tiled, const void* d_bf16, int64_t
   const size_t lds = (size_t)pl.QB * BSTEPS * 64 * 16 + (size_t)pl.QB * 32 * 11 * sizeof(int);
   if (ev_scan_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_scan_begin), st);
   const void* kern = nullptr;
+#ifdef SSKD_SCREEN_FORCE_LK
+  if (pl.QB == 4) kern = reinterpret_cast<const void*>(screen_topk_kernel<10, 4, SCREEN_WAVES, SSKD_SCREEN_FORCE_LK>);
+  else kern = reinterpret_cast<const void*>(screen_topk_kernel<10, 2, SCREEN_WAVES, SSKD_SCREEN_FORCE_LK>);
+  if (false)
+#endif
   if (pl.QB == 4 && pl.LK == 8) kern = reinterpret_cast<const void*>(screen_topk_kernel<10, 4, SCREEN_WAVES, 8>);
   else if (pl.QB == 4 && pl.LK == 6) kern = reinterpret_cast<const void*>(screen_topk_kernel<10, 4, SCREEN_WAVES, 6>);
   else if (pl.QB == 2 && pl.LK == 8) kern = reinterpret_cast<const void*>(screen_topk_kernel<10, 2, SCREEN_WAVES, 8>);

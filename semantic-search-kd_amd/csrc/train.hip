@@ -25,6 +25,7 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct Dims {
   int B, S, H, NH, DH, F, L;
   int64_t M;
+  bool training;  // false: nothing is kept for a backward pass (fused attention, GELU in the GEMM epilogue)
 };
 
 struct LayerSaved {
@@ -66,13 +67,13 @@ Saved carve(void* base, const Dims& d, LayerSaved* layers_out, bool training) {
   for (int l = 0; l < nl; ++l) {
     LayerSaved& ls = layers_out[l];
     ls.qkv = take_b(3 * MH);
-    ls.P = take_b(PP);
+    ls.P = training ? take_b(PP) : nullptr;     // inference: fused attention, no score matrix
     ls.ctx = take_b(MH);
-    ls.z1 = take_b(MH);
+    ls.z1 = training ? take_b(MH) : nullptr;
     ls.x1 = take_b(MH);
-    ls.u = take_b(MF);
+    ls.u = training ? take_b(MF) : nullptr;     // inference: GELU in the GEMM epilogue
     ls.hmid = take_b(MF);
-    ls.z2 = take_b(MH);
+    ls.z2 = training ? take_b(MH) : nullptr;
     ls.x2 = take_b(MH);
     ls.mean1 = take_f(M);
     ls.rstd1 = take_f(M);
@@ -88,7 +89,7 @@ Saved carve(void* base, const Dims& d, LayerSaved* layers_out, bool training) {
     for (int l = 1; l < d.L; l += 2) layers_out[l].x2 = alt;
   }
   s.tH0 = take_b(MH);
-  s.vt = take_b(MH);
+  s.vt = training ? take_b(MH) : nullptr;
   if (training) {
     s.tH1 = take_b(MH);
     s.tH2 = take_b(MH);
@@ -180,6 +181,30 @@ int layer_forward(const Dims& d, const sskd_generic_layer_weights& lw, float eps
   const int H = d.H, S = d.S, DH = d.DH, NH = d.NH, F = d.F;
   const int64_t M = d.M;
   TRY(gemm(x, H, static_cast<const bf16_t*>(lw.wqkv), H, ls.qkv, 3 * H, M, 3 * H, H, lw.bqkv, false, false, st));
+  if (!d.training) {
+    // inference: scores, softmax and P V in one kernel (no [B, heads, S, S] matrix), GELU inside FFN1's epilogue
+    TRY(launch_attention_fwd(ls.qkv, mask, d.B, S, NH, DH, 1.0f / sqrtf((float)DH), ls.ctx, st));
+    TRY(gemm(ls.ctx, H, static_cast<const bf16_t*>(lw.wo), H, sv.tH0, H, M, H, H, lw.bo, false, false, st));
+    TRY(launch_add_ln_fwd(x, sv.tH0, lw.ln1_g, lw.ln1_b, eps, M, H, ls.x1, nullptr, nullptr, nullptr, st));
+    GemmArgs f1{};
+    f1.A = ls.x1;
+    f1.B = static_cast<const bf16_t*>(lw.w1);
+    f1.C = ls.hmid;
+    f1.bias = lw.b1;
+    f1.M = (int)M;
+    f1.N = F;
+    f1.K = H;
+    f1.lda = H;
+    f1.ldb = H;
+    f1.ldc = F;
+    f1.batch1 = f1.batch2 = 1;
+    f1.alpha = 1.0f;
+    f1.act = 1;
+    TRY(launch_gemm_nt(f1, st));
+    TRY(gemm(ls.hmid, F, static_cast<const bf16_t*>(lw.w2), F, sv.tH0, H, M, H, F, lw.b2, false, false, st));
+    TRY(launch_add_ln_fwd(ls.x1, sv.tH0, lw.ln2_g, lw.ln2_b, eps, M, H, ls.x2, nullptr, nullptr, nullptr, st));
+    return SSKD_OK;
+  }
   // scores[b, h] = Q_bh K_bh^T
   GemmArgs g{};
   g.A = ls.qkv;
@@ -440,6 +465,7 @@ static int prepare(const sskd_generic_config* cfg, const sskd_generic_weights* w
                    void* d_workspace, size_t workspace_bytes, Dims* d, std::vector<LayerSaved>* layers, Saved* sv) {
   int rc = check(cfg, w, B, S, d);
   if (rc != SSKD_OK) return rc;
+  d->training = training != 0;
   SSKD_REQUIRE(w->word_emb && w->pos_emb && w->type_emb && w->emb_ln_g && w->emb_ln_b && (cfg->layers == 0 || w->layers),
                "generic encoder: null weight pointer");
   if (B == 0) return SSKD_OK;

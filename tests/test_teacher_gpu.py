@@ -88,6 +88,48 @@ def test_teacher_large_shape_layers_vs_oracle(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("hidden,heads,S,lengths", [
+    (256, 2, 96, [96, 61, 33, 5]),        # head width 128, three key tiles, one workgroup per (row, head)
+    (128, 4, 512, [512, 300, 257, 32]),   # head width 32, 16 query tiles = two workgroups per (row, head)
+    (128, 2, 288, [288, 200, 31]),        # head width 64, nine tiles: the second workgroup has one active wave
+])
+def test_inference_forward_fused_attention_shapes(gpu, hidden, heads, S, lengths):
+    """The inference forward runs attention as one fused kernel (no score matrix) and GELU inside FFN1's
+    epilogue: hold the hidden states of every real token to the oracle across head widths, tile counts and
+    ragged key masks (rows with masked tails exercise the skipped key tiles and the additive bias)."""
+    from semantic_search_kd_amd import TeacherConfig, TeacherModel, _native
+    from semantic_search_kd_amd.teacher import synthetic_teacher_state_dict
+
+    cfg = TeacherConfig(vocab_size=900, hidden_size=hidden, num_hidden_layers=2, num_attention_heads=heads,
+                        intermediate_size=2 * hidden, max_position_embeddings=S + 4)
+    sd = synthetic_teacher_state_dict(cfg)
+    B = len(lengths)
+    ids, mask = _case(cfg, B, S, lengths, seed=S + hidden)
+    teacher = TeacherModel("synthetic", "cuda:0", config=cfg, state_dict=sd)
+    lib = _native.load()
+    out = torch.empty((B, S, hidden), dtype=torch.bfloat16, device="cuda")
+    d_ids, d_mask = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
+    ws = torch.empty(int(lib.sskd_generic_workspace_bytes(teacher._cfg, B, S, 0)), dtype=torch.uint8, device="cuda")
+    _native.check(lib.sskd_generic_forward(teacher._cfg, teacher._w, d_ids.data_ptr(), d_mask.data_ptr(), B, S, 0, 0, 0,
+                                           out.data_ptr(), ws.data_ptr(), ws.numel(), int(torch.cuda.current_stream().cuda_stream)))
+    t = {k: torch.from_numpy(v) for k, v in sd.items()}
+    ref = enc_oracle.bert_hidden_states_torch(t, ids, mask, 2, heads, cfg.layer_norm_eps, pos_offset=2)[-1].numpy()
+    h = out.float().cpu().numpy()
+    m = mask.astype(bool)
+    assert np.isfinite(h).all()
+    cos = (h[m] * ref[m]).sum(1) / (np.linalg.norm(h[m], axis=1) * np.linalg.norm(ref[m], axis=1))
+    assert cos.min() >= 0.999, cos.min()
+    # the training-mode forward (unfused, activations saved) must agree with the fused one
+    out_t = torch.empty_like(out)
+    ws_t = torch.empty(int(lib.sskd_generic_workspace_bytes(teacher._cfg, B, S, 1)), dtype=torch.uint8, device="cuda")
+    _native.check(lib.sskd_generic_forward(teacher._cfg, teacher._w, d_ids.data_ptr(), d_mask.data_ptr(), B, S, 1, 0, 0,
+                                           out_t.data_ptr(), ws_t.data_ptr(), ws_t.numel(), int(torch.cuda.current_stream().cuda_stream)))
+    ht = out_t.float().cpu().numpy()
+    cos_t = (h[m] * ht[m]).sum(1) / (np.linalg.norm(h[m], axis=1) * np.linalg.norm(ht[m], axis=1))
+    assert cos_t.min() >= 0.9995, cos_t.min()
+
+
+@pytest.mark.gpu
 def test_teacher_score_pairs_api_and_rerank_route(gpu):
     """score(pairs) (lists or tuples, any batch_size), predict / predict_score aliases, and the /search
     rerank branch (reference: src/serve/app.py:321-339) driving the real teacher object."""

@@ -58,6 +58,7 @@ for r in range(7):
         times[n].append(ms.value)
         if ref is None:
             ref = (out_s.clone(), out_i.clone())
-        assert torch.equal(out_i, ref[1]) and torch.equal(out_s, ref[0]) and int(status[0]) == 0, n
+        if not os.environ.get('AB_NOCHECK'):
+            assert torch.equal(out_i, ref[1]) and torch.equal(out_s, ref[0]) and int(status[0]) == 0, n
 for n in times:
     print(f"{n}: screen kernel median {np.median(times[n][1:]):.3f} ms (min {np.min(times[n][1:]):.3f}); whole call {np.median(wall[n][1:]):.3f} ms", flush=True)
