@@ -38,6 +38,8 @@ struct TransposeArgs {
   int64_t ld_in, ld_out;
   int batch1, batch2;
   int64_t sI1, sI2, sO1, sO2;
+  float* colsum;   // optional (unbatched): colsum[c] += sum_r in[r][c] (fp32 atomics) - the bias gradient of the
+                   // product whose operand is being transposed, without a second pass over it
 };
 int launch_transpose(const TransposeArgs& a, hipStream_t st);
 
@@ -52,8 +54,17 @@ int launch_ln_bwd(const bf16_t* dy, const bf16_t* z, const float* mean, const fl
 //   ctx[b, :, h*DH : (h+1)*DH] = softmax(scale * Q K^T + (key masked ? -inf : 0)) V
 // with Q / K / V the column blocks [0, H) / [H, 2H) / [2H, 3H) of the row-major qkv [B*S, 3H].
 // DH in {32, 64, 128}; S a multiple of 32, at most 512.
+// `lse` (optional, fp32 [B, heads, S]): log2-domain log-sum-exp of every query's scaled scores - all the
+// backward kernel needs to rebuild the probabilities.
 int launch_attention_fwd(const bf16_t* qkv, const int32_t* key_mask, int B, int S, int heads, int DH, float scale,
-                         bf16_t* ctx, hipStream_t st);
+                         bf16_t* ctx, float* lse, hipStream_t st);
+// Fused attention backward (probabilities recomputed from qkv + lse, no S x S matrix in memory):
+//   dqkv[:, 0:H | H:2H | 2H:3H] = dQ | dK | dV  given dctx, with ctx the forward output.
+// One workgroup per (batch row, head) keeps the head's Q, K, V, dO (and three transposed copies) in LDS:
+// served for S * DH <= 8192 (attention_bwd_supported), e.g. the student (DH 32, S <= 256).
+bool attention_bwd_supported(int S, int DH);
+int launch_attention_bwd(const bf16_t* qkv, const int32_t* key_mask, const bf16_t* ctx, const bf16_t* dctx,
+                         const float* lse, int B, int S, int heads, int DH, float scale, bf16_t* dqkv, hipStream_t st);
 
 // rows of S scores (bf16, in place): P = softmax(scale * s + (key masked ? -inf : 0)).
 int launch_softmax_fwd(bf16_t* scores, const int32_t* key_mask, int B, int heads, int S, float scale, hipStream_t st);

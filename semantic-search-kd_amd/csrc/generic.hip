@@ -188,6 +188,7 @@ struct AttnArgs {
   const bf16_t* qkv;
   const int32_t* mask;
   bf16_t* ctx;
+  float* lse;   // optional [B, NH, S]
   int B, S, NH, H;
   int nkt;      // S / 32
   int qsplit;   // workgroups per (row, head): ceil(nkt / 8)
@@ -303,6 +304,7 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnArgs p) {
   }
   l = pair_sum32(l);
   const float inv = l > 0.f ? 1.0f / l : 0.f;
+  if (p.lse && h == 0) p.lse[((int64_t)b * p.NH + head) * p.S + qt * 32 + j] = m + log2f(l);
   // o[t][4g + e] = O[query = lane & 31][dim 32t + 8g + 4h + e]: 4 consecutive dims = one 8-byte store
   bf16_t* out = p.ctx + (row0 + qt * 32 + j) * (int64_t)p.H + (int64_t)head * DH;
 #pragma unroll
@@ -317,6 +319,227 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------- //
+// Fused attention backward.  One workgroup = one (batch row, head), S <= 256 (8 tiles, one per wave).
+// The probabilities are rebuilt from Q, K and the saved log-sum-exp, in two passes so that every
+// accumulation is wave-local (no atomics):
+//   pass A  wave = QUERY tile, loop over key tiles (the forward's geometry: query on the lane)
+//     S^T  = K Q^T, dP^T = V dO^T           A = row fragments of K / V (LDS), B = Q^T / dO^T (registers)
+//     dS^T = P^T o (dP^T - D) scale         lse and D = rowsum(dO o O) are lane-local
+//     dQ^T += K^T dS^T                      B = the packed dS^T accumulators, A = K^T in their key order
+//   pass B  wave = KEY tile, loop over query tiles (key on the lane)
+//     S = Q K^T, dP = dO V^T                A = row fragments of Q / dO (LDS), B = K^T / V^T (registers)
+//     dV^T += dO^T P, dK^T += Q^T dS        B = packed P / dS accumulators, A = dO^T / Q^T in their query order
+// ------------------------------------------------------------------------- //
+struct AttnBwdArgs {
+  const bf16_t* qkv;
+  const int32_t* mask;
+  const bf16_t* ctx;
+  const bf16_t* dctx;
+  const float* lse;
+  bf16_t* dqkv;
+  int B, S, NH, H, nkt;
+  float scale, scale2;
+};
+
+// row-major [rows][DH] block of a head -> MFMA row fragments (A operand rows = block rows, B operand columns = block rows)
+template <int DH>
+__device__ inline void stage_row_frags(bf16x8* dst, const bf16_t* src, int64_t ld, int S, int tid) {
+  constexpr int CPK = DH / 8, KS = DH / 16;
+  for (int v = tid; v < S * CPK; v += 512) {
+    const int row = v / CPK, c = v - row * CPK;
+    dst[((row >> 5) * KS + (c >> 1)) * 64 + (row & 31) + 32 * (c & 1)] =
+        *reinterpret_cast<const bf16x8*>(src + (int64_t)row * ld + 8 * c);
+  }
+}
+// the same block transposed: A-operand fragments [dim][row] with the rows of a 32-tile in the order the packed
+// accumulators present them (k index 8h + e' <-> row 16 s2 + 8 (e' >> 2) + 4h + (e' & 3))
+template <int DH>
+__device__ inline void stage_transposed_frags(bf16_t* dst, const bf16_t* src, int64_t ld, int S, int tid) {
+  constexpr int CPK = DH / 8, DT = DH / 32;
+  for (int v = tid; v < S * CPK; v += 512) {
+    const int row = v / CPK, c = v - row * CPK;
+    const bf16x8 vv = *reinterpret_cast<const bf16x8*>(src + (int64_t)row * ld + 8 * c);
+    const int kk = row & 31, g = kk >> 3, hh = (kk >> 2) & 1, e = kk & 3;
+    const int s2 = g >> 1, ep = 4 * (g & 1) + e;
+#pragma unroll
+    for (int e8 = 0; e8 < 8; ++e8) {
+      const int d = 8 * c + e8;
+      dst[(((((row >> 5) * DT + (d >> 5)) * 2 + s2) * 64) + (d & 31) + 32 * hh) * 8 + ep] = vv[e8];
+    }
+  }
+}
+
+template <int DH>
+__global__ __launch_bounds__(512) void attention_bwd_kernel(AttnBwdArgs p) {
+  constexpr int KS = DH / 16, DT = DH / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char att_lds[];
+  const int SD8 = p.S * DH / 8;  // bf16x8 vectors of one [S][DH] block
+  bf16x8* const kA = reinterpret_cast<bf16x8*>(att_lds);
+  bf16x8* const vA = kA + SD8;
+  bf16x8* const qA = vA + SD8;
+  bf16x8* const doA = qA + SD8;
+  bf16x8* const kT = doA + SD8;
+  bf16x8* const qT = kT + SD8;
+  bf16x8* const doT = qT + SD8;
+  float* const lse = reinterpret_cast<float*>(doT + SD8);
+  float* const Dq = lse + p.S;
+  float* const mb = Dq + p.S;
+  __shared__ int s_kmax;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int head = blockIdx.x % p.NH, b = blockIdx.x / p.NH;
+  const int64_t row0 = (int64_t)b * p.S;
+  const int64_t ld = 3 * (int64_t)p.H;
+  const bf16_t* qbase = p.qkv + row0 * ld + (int64_t)head * DH;
+  const bf16_t* obase = p.ctx + row0 * p.H + (int64_t)head * DH;
+  const bf16_t* dobase = p.dctx + row0 * p.H + (int64_t)head * DH;
+
+  if (tid == 0) s_kmax = 0;
+  __syncthreads();
+  for (int i = tid; i < p.S; i += 512) {
+    const bool on = p.mask[row0 + i] != 0;
+    mb[i] = on ? 0.f : ATT_NEG;
+    if (on) atomicMax(&s_kmax, i / 32 + 1);
+    lse[i] = p.lse[((int64_t)b * p.NH + head) * p.S + i];
+    float dsum = 0.f;
+#pragma unroll
+    for (int c = 0; c < DH / 8; ++c) {
+      const bf16x8 o = *reinterpret_cast<const bf16x8*>(obase + (int64_t)i * p.H + 8 * c);
+      const bf16x8 g = *reinterpret_cast<const bf16x8*>(dobase + (int64_t)i * p.H + 8 * c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dsum = fmaf((float)o[e], (float)g[e], dsum);
+    }
+    Dq[i] = dsum;
+  }
+  stage_row_frags<DH>(kA, qbase + p.H, ld, p.S, tid);
+  stage_row_frags<DH>(vA, qbase + 2 * p.H, ld, p.S, tid);
+  stage_row_frags<DH>(qA, qbase, ld, p.S, tid);
+  stage_row_frags<DH>(doA, dobase, p.H, p.S, tid);
+  stage_transposed_frags<DH>(reinterpret_cast<bf16_t*>(kT), qbase + p.H, ld, p.S, tid);
+  stage_transposed_frags<DH>(reinterpret_cast<bf16_t*>(qT), qbase, ld, p.S, tid);
+  stage_transposed_frags<DH>(reinterpret_cast<bf16_t*>(doT), dobase, p.H, p.S, tid);
+  __syncthreads();
+  if (wave >= p.nkt) return;
+  const int kmax = s_kmax;
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  bf16_t* const drow = p.dqkv + (row0 + wave * 32 + j) * ld + (int64_t)head * DH;  // this lane's row of dQ | dK | dV
+
+  // ---- pass A: dQ of query tile `wave` ----
+  {
+    bf16x8 qB[KS], doB[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      qB[s] = qA[(wave * KS + s) * 64 + lane];     // B operand of a row block = its row fragment
+      doB[s] = doA[(wave * KS + s) * 64 + lane];
+    }
+    const float lse_q = lse[wave * 32 + j], d_q = Dq[wave * 32 + j];
+    f32x16 dq[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dq[t][i] = 0.f;
+    for (int kt = 0; kt < kmax; ++kt) {
+      f32x16 st, dpt;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) st[i] = dpt[i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kA[(kt * KS + s) * 64 + lane], qB[s], st, 0, 0, 0);
+        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vA[(kt * KS + s) * 64 + lane], doB[s], dpt, 0, 0, 0);
+      }
+      bf16x8 dsf[2];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 bias = *reinterpret_cast<const float4*>(&mb[kt * 32 + 8 * g + 4 * h]);
+        const float bb[4] = {bias.x, bias.y, bias.z, bias.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = 4 * g + e;
+          const float pr = __builtin_amdgcn_exp2f(fmaf(st[i], p.scale2, bb[e]) - lse_q);
+          dsf[i >> 3][i & 7] = (bf16_t)(pr * (dpt[i] - d_q) * p.scale);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        dq[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT[((kt * DT + t) * 2 + 0) * 64 + lane], dsf[0], dq[t], 0, 0, 0);
+        dq[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT[((kt * DT + t) * 2 + 1) * 64 + lane], dsf[1], dq[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = (bf16_t)dq[t][4 * g + e];
+        *reinterpret_cast<bf16x4*>(drow + 32 * t + 8 * g + 4 * h) = w;
+      }
+  }
+
+  // ---- pass B: dK, dV of key tile `wave` ----
+  {
+    bf16x8 kB[KS], vB[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      kB[s] = kA[(wave * KS + s) * 64 + lane];
+      vB[s] = vA[(wave * KS + s) * 64 + lane];
+    }
+    const float mbk = mb[wave * 32 + j];
+    f32x16 dk[DT], dv[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dk[t][i] = dv[t][i] = 0.f;
+    const int qmax = wave < kmax ? kmax : 0;  // a fully masked key tile gets zero gradients
+    for (int qt = 0; qt < qmax; ++qt) {
+      f32x16 sq, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sq[i] = dp[i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        sq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qA[(qt * KS + s) * 64 + lane], kB[s], sq, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doA[(qt * KS + s) * 64 + lane], vB[s], dp, 0, 0, 0);
+      }
+      bf16x8 pf[2], dsf[2];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 l4 = *reinterpret_cast<const float4*>(&lse[qt * 32 + 8 * g + 4 * h]);
+        const float4 d4 = *reinterpret_cast<const float4*>(&Dq[qt * 32 + 8 * g + 4 * h]);
+        const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = 4 * g + e;
+          const float pr = __builtin_amdgcn_exp2f(fmaf(sq[i], p.scale2, mbk) - ll[e]);
+          pf[i >> 3][i & 7] = (bf16_t)pr;
+          dsf[i >> 3][i & 7] = (bf16_t)(pr * (dp[i] - dd[e]) * p.scale);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        dv[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doT[((qt * DT + t) * 2 + 0) * 64 + lane], pf[0], dv[t], 0, 0, 0);
+        dv[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doT[((qt * DT + t) * 2 + 1) * 64 + lane], pf[1], dv[t], 0, 0, 0);
+        dk[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qT[((qt * DT + t) * 2 + 0) * 64 + lane], dsf[0], dk[t], 0, 0, 0);
+        dk[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qT[((qt * DT + t) * 2 + 1) * 64 + lane], dsf[1], dk[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 wk, wv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          wk[e] = (bf16_t)dk[t][4 * g + e];
+          wv[e] = (bf16_t)dv[t][4 * g + e];
+        }
+        *reinterpret_cast<bf16x4*>(drow + p.H + 32 * t + 8 * g + 4 * h) = wk;
+        *reinterpret_cast<bf16x4*>(drow + 2 * p.H + 32 * t + 8 * g + 4 * h) = wv;
+      }
+  }
+}
+
 // 64 x 64 tiles through LDS; both the loads and the stores move 8 bytes per thread in 128-byte row
 // segments (R, C, leading dimensions and batch strides are multiples of 4 on this path)
 __global__ __launch_bounds__(256) void transpose_kernel(TransposeArgs p) {
@@ -324,8 +547,11 @@ __global__ __launch_bounds__(256) void transpose_kernel(TransposeArgs p) {
   const int z = blockIdx.z, b1 = z / p.batch2, b2 = z - b1 * p.batch2;
   const unsigned short* in = reinterpret_cast<const unsigned short*>(p.in) + b1 * p.sI1 + b2 * p.sI2;
   unsigned short* out = reinterpret_cast<unsigned short*>(p.out) + b1 * p.sO1 + b2 * p.sO2;
+  __shared__ float colacc[64];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  if (p.colsum && threadIdx.x < 64) colacc[threadIdx.x] = 0.f;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};  // this thread's 4 columns over its 4 rows
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = r0 + ty + 16 * i, c = c0 + tx * 4;
@@ -338,8 +564,24 @@ __global__ __launch_bounds__(256) void transpose_kernel(TransposeArgs p) {
     unsigned int* dst = reinterpret_cast<unsigned int*>(&tile[ty + 16 * i][tx * 4]);
     dst[0] = lo;
     dst[1] = hi;
+    cs[0] += __uint_as_float(lo << 16);
+    cs[1] += __uint_as_float(lo & 0xffff0000u);
+    cs[2] += __uint_as_float(hi << 16);
+    cs[3] += __uint_as_float(hi & 0xffff0000u);
   }
   __syncthreads();
+  if (p.colsum) {
+    // lanes tx + 16 k of a wave hold the same columns: fold them (2 steps), then one LDS atomic per wave and column
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      cs[e] += __shfl_xor(cs[e], 16);
+      cs[e] += __shfl_xor(cs[e], 32);
+    }
+    if ((threadIdx.x & 63) < 16) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(&colacc[tx * 4 + e], cs[e]);
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = c0 + ty + 16 * i, r = r0 + tx * 4;
@@ -350,6 +592,10 @@ __global__ __launch_bounds__(256) void transpose_kernel(TransposeArgs p) {
       v.y = (unsigned int)tile[lr + 2][lc] | ((unsigned int)tile[lr + 3][lc] << 16);
       *reinterpret_cast<uint2*>(out + (int64_t)c * p.ld_out + r) = v;
     }
+  }
+  if (p.colsum) {
+    __syncthreads();
+    if (threadIdx.x < 64 && c0 + threadIdx.x < p.C) atomicAdd(p.colsum + c0 + threadIdx.x, colacc[threadIdx.x]);
   }
 }
 
@@ -806,7 +1052,7 @@ int launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
 }
 
 int launch_attention_fwd(const bf16_t* qkv, const int32_t* key_mask, int B, int S, int heads, int DH, float scale,
-                         bf16_t* ctx, hipStream_t st) {
+                         bf16_t* ctx, float* lse, hipStream_t st) {
   if (B == 0) return SSKD_OK;
   SSKD_REQUIRE(qkv && key_mask && ctx, "attention_fwd: null pointer");
   SSKD_REQUIRE(S >= 32 && S % 32 == 0 && S <= 512, "attention_fwd: S=%d must be a multiple of 32 in [32, 512]", S);
@@ -815,6 +1061,7 @@ int launch_attention_fwd(const bf16_t* qkv, const int32_t* key_mask, int B, int 
   a.qkv = qkv;
   a.mask = key_mask;
   a.ctx = ctx;
+  a.lse = lse;
   a.B = B;
   a.S = S;
   a.NH = heads;
@@ -834,11 +1081,45 @@ int launch_attention_fwd(const bf16_t* qkv, const int32_t* key_mask, int B, int 
   return sskd::check_launch("attention_fwd_kernel");
 }
 
+bool attention_bwd_supported(int S, int DH) {
+  return (DH == 32 || DH == 64) && S >= 32 && S % 32 == 0 && S <= 256 && S * DH <= 8192;
+}
+
+int launch_attention_bwd(const bf16_t* qkv, const int32_t* key_mask, const bf16_t* ctx, const bf16_t* dctx,
+                         const float* lse, int B, int S, int heads, int DH, float scale, bf16_t* dqkv, hipStream_t st) {
+  if (B == 0) return SSKD_OK;
+  SSKD_REQUIRE(qkv && key_mask && ctx && dctx && lse && dqkv, "attention_bwd: null pointer");
+  SSKD_REQUIRE(attention_bwd_supported(S, DH), "attention_bwd: S=%d, head width %d not served (S * DH <= 8192)", S, DH);
+  AttnBwdArgs a{};
+  a.qkv = qkv;
+  a.mask = key_mask;
+  a.ctx = ctx;
+  a.dctx = dctx;
+  a.lse = lse;
+  a.dqkv = dqkv;
+  a.B = B;
+  a.S = S;
+  a.NH = heads;
+  a.H = heads * DH;
+  a.nkt = S / 32;
+  a.scale = scale;
+  a.scale2 = scale * 1.4426950408889634f;
+  const size_t lds = (size_t)7 * S * DH * 2 + (size_t)3 * S * sizeof(float);
+  auto go = [&](auto kern) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(B * heads)), dim3(512), lds, st, a);
+  };
+  if (DH == 32) go(attention_bwd_kernel<32>);
+  else go(attention_bwd_kernel<64>);
+  return sskd::check_launch("attention_bwd_kernel");
+}
+
 int launch_transpose(const TransposeArgs& a, hipStream_t st) {
   if (a.R == 0 || a.C == 0) return SSKD_OK;
   SSKD_REQUIRE(a.R % 4 == 0 && a.C % 4 == 0 && a.ld_in % 4 == 0 && a.ld_out % 4 == 0 && a.sI1 % 4 == 0 && a.sI2 % 4 == 0 &&
                    a.sO1 % 4 == 0 && a.sO2 % 4 == 0,
                "transpose: shapes and strides must be multiples of 4");
+  SSKD_REQUIRE(!a.colsum || a.batch1 * a.batch2 == 1, "transpose: the column-sum side output is for unbatched calls");
   const dim3 grid((unsigned)sskd::ceil_div(a.C, 64), (unsigned)sskd::ceil_div(a.R, 64), (unsigned)(a.batch1 * a.batch2));
   hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, st, a);
   return sskd::check_launch("transpose_kernel");

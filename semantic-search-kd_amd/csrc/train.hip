@@ -31,6 +31,7 @@ struct Dims {
 struct LayerSaved {
   bf16_t *qkv, *P, *ctx, *z1, *x1, *u, *hmid, *z2, *x2;
   float *mean1, *rstd1, *mean2, *rstd2;
+  float* lse;  // fused attention (training): log-sum-exp per (row, head, query) instead of P
 };
 
 struct Saved {
@@ -58,6 +59,8 @@ Saved carve(void* base, const Dims& d, LayerSaved* layers_out, bool training) {
   const size_t M = (size_t)d.M, MH = M * d.H, MF = M * d.F, PP = (size_t)d.B * d.NH * d.S * d.S;
   Saved s{};
   s.layer = layers_out;
+  // training with the fused attention kernels keeps lse [B, heads, S] instead of the S x S probabilities
+  const bool flash = training && attention_bwd_supported(d.S, d.DH);
   s.z0 = take_b(MH);
   s.x0 = take_b(MH);
   s.mean0 = take_f(M);
@@ -67,7 +70,8 @@ Saved carve(void* base, const Dims& d, LayerSaved* layers_out, bool training) {
   for (int l = 0; l < nl; ++l) {
     LayerSaved& ls = layers_out[l];
     ls.qkv = take_b(3 * MH);
-    ls.P = training ? take_b(PP) : nullptr;     // inference: fused attention, no score matrix
+    ls.P = (training && !flash) ? take_b(PP) : nullptr;  // fused attention: no score matrix
+    ls.lse = flash ? take_f((size_t)d.B * d.NH * d.S) : nullptr;
     ls.ctx = take_b(MH);
     ls.z1 = training ? take_b(MH) : nullptr;
     ls.x1 = take_b(MH);
@@ -94,8 +98,8 @@ Saved carve(void* base, const Dims& d, LayerSaved* layers_out, bool training) {
     s.tH1 = take_b(MH);
     s.tH2 = take_b(MH);
     s.tF0 = take_b(MF);
-    s.tP0 = take_b(PP);
-    s.tP1 = take_b(PP);
+    s.tP0 = flash ? nullptr : take_b(PP);
+    s.tP1 = flash ? nullptr : take_b(PP);
     const size_t wide = (size_t)(3 * d.H > d.F ? 3 * d.H : d.F);
     s.tA = take_b(wide * M);
     s.tB = take_b((size_t)(d.H > d.F ? d.H : d.F) * M);
@@ -149,7 +153,10 @@ int gemm(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, in
   // workgroups to fill the chip; the slices meet through fp32 atomics
   if (acc && c_f32 && !bias) {
     const int64_t tiles = sskd::ceil_div(M, 128) * sskd::ceil_div(N, 128);
-    int split = (int)(1024 / (tiles > 0 ? tiles : 1));
+#ifndef SSKD_SPLITK_TARGET
+#define SSKD_SPLITK_TARGET 256  // one workgroup per CU: every extra slice adds a 128 x 128 tile of device-scope atomics (1024: 104 us, 256: 65 us for 384 x 384 x 65 k)
+#endif
+    int split = (int)(SSKD_SPLITK_TARGET / (tiles > 0 ? tiles : 1));
     const int max_split = K / 256;  // at least 256 of K per slice
     if (split > max_split) split = max_split;
     g.split_k = split > 1 ? split : 1;
@@ -157,8 +164,10 @@ int gemm(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, in
   return launch_gemm_nt(g, st);
 }
 
-int transpose2d(const bf16_t* in, int64_t R, int C, int64_t ld_in, bf16_t* out, int64_t ld_out, hipStream_t st) {
+int transpose2d(const bf16_t* in, int64_t R, int C, int64_t ld_in, bf16_t* out, int64_t ld_out, hipStream_t st,
+                float* colsum = nullptr) {
   TransposeArgs t{};
+  t.colsum = colsum;
   t.in = in;
   t.out = out;
   t.R = (int)R;
@@ -176,6 +185,20 @@ int transpose2d(const bf16_t* in, int64_t R, int C, int64_t ld_in, bf16_t* out, 
   } while (0)
 
 // ---- forward of one layer: x -> ls.x2, saving what the backward needs -------------------------
+// everything after attention of a TRAINING forward (activations saved): out-projection, LN, FFN, LN
+int layer_forward_tail(const Dims& d, const sskd_generic_layer_weights& lw, float eps, const bf16_t* x, LayerSaved& ls,
+                       Saved& sv, hipStream_t st) {
+  const int H = d.H, F = d.F;
+  const int64_t M = d.M;
+  TRY(gemm(ls.ctx, H, static_cast<const bf16_t*>(lw.wo), H, sv.tH0, H, M, H, H, lw.bo, false, false, st));
+  TRY(launch_add_ln_fwd(x, sv.tH0, lw.ln1_g, lw.ln1_b, eps, M, H, ls.x1, ls.z1, ls.mean1, ls.rstd1, st));
+  TRY(gemm(ls.x1, H, static_cast<const bf16_t*>(lw.w1), H, ls.u, F, M, F, H, lw.b1, false, false, st));
+  TRY(launch_gelu_fwd(ls.u, ls.hmid, M * F, st));
+  TRY(gemm(ls.hmid, F, static_cast<const bf16_t*>(lw.w2), F, sv.tH0, H, M, H, F, lw.b2, false, false, st));
+  TRY(launch_add_ln_fwd(ls.x1, sv.tH0, lw.ln2_g, lw.ln2_b, eps, M, H, ls.x2, ls.z2, ls.mean2, ls.rstd2, st));
+  return SSKD_OK;
+}
+
 int layer_forward(const Dims& d, const sskd_generic_layer_weights& lw, float eps, const bf16_t* x, const int32_t* mask,
                   LayerSaved& ls, Saved& sv, hipStream_t st) {
   const int H = d.H, S = d.S, DH = d.DH, NH = d.NH, F = d.F;
@@ -183,7 +206,7 @@ int layer_forward(const Dims& d, const sskd_generic_layer_weights& lw, float eps
   TRY(gemm(x, H, static_cast<const bf16_t*>(lw.wqkv), H, ls.qkv, 3 * H, M, 3 * H, H, lw.bqkv, false, false, st));
   if (!d.training) {
     // inference: scores, softmax and P V in one kernel (no [B, heads, S, S] matrix), GELU inside FFN1's epilogue
-    TRY(launch_attention_fwd(ls.qkv, mask, d.B, S, NH, DH, 1.0f / sqrtf((float)DH), ls.ctx, st));
+    TRY(launch_attention_fwd(ls.qkv, mask, d.B, S, NH, DH, 1.0f / sqrtf((float)DH), ls.ctx, nullptr, st));
     TRY(gemm(ls.ctx, H, static_cast<const bf16_t*>(lw.wo), H, sv.tH0, H, M, H, H, lw.bo, false, false, st));
     TRY(launch_add_ln_fwd(x, sv.tH0, lw.ln1_g, lw.ln1_b, eps, M, H, ls.x1, nullptr, nullptr, nullptr, st));
     GemmArgs f1{};
@@ -204,6 +227,11 @@ int layer_forward(const Dims& d, const sskd_generic_layer_weights& lw, float eps
     TRY(gemm(ls.hmid, F, static_cast<const bf16_t*>(lw.w2), F, sv.tH0, H, M, H, F, lw.b2, false, false, st));
     TRY(launch_add_ln_fwd(ls.x1, sv.tH0, lw.ln2_g, lw.ln2_b, eps, M, H, ls.x2, nullptr, nullptr, nullptr, st));
     return SSKD_OK;
+  }
+  if (ls.lse) {
+    // fused attention that keeps the log-sum-exp for the fused backward
+    TRY(launch_attention_fwd(ls.qkv, mask, d.B, S, NH, DH, 1.0f / sqrtf((float)DH), ls.ctx, ls.lse, st));
+    return layer_forward_tail(d, lw, eps, x, ls, sv, st);
   }
   // scores[b, h] = Q_bh K_bh^T
   GemmArgs g{};
@@ -260,13 +288,7 @@ int layer_forward(const Dims& d, const sskd_generic_layer_weights& lw, float eps
   c.sC2 = DH;
   c.alpha = 1.0f;
   TRY(launch_gemm_nt(c, st));
-  TRY(gemm(ls.ctx, H, static_cast<const bf16_t*>(lw.wo), H, sv.tH0, H, M, H, H, lw.bo, false, false, st));
-  TRY(launch_add_ln_fwd(x, sv.tH0, lw.ln1_g, lw.ln1_b, eps, M, H, ls.x1, ls.z1, ls.mean1, ls.rstd1, st));
-  TRY(gemm(ls.x1, H, static_cast<const bf16_t*>(lw.w1), H, ls.u, F, M, F, H, lw.b1, false, false, st));
-  TRY(launch_gelu_fwd(ls.u, ls.hmid, M * F, st));
-  TRY(gemm(ls.hmid, F, static_cast<const bf16_t*>(lw.w2), F, sv.tH0, H, M, H, F, lw.b2, false, false, st));
-  TRY(launch_add_ln_fwd(ls.x1, sv.tH0, lw.ln2_g, lw.ln2_b, eps, M, H, ls.x2, ls.z2, ls.mean2, ls.rstd2, st));
-  return SSKD_OK;
+  return layer_forward_tail(d, lw, eps, x, ls, sv, st);
 }
 
 int forward_all(const sskd_generic_config* cfg, const sskd_generic_weights* w, const Dims& d, const int32_t* ids,
@@ -284,25 +306,35 @@ int forward_all(const sskd_generic_config* cfg, const sskd_generic_weights* w, c
   return SSKD_OK;
 }
 
+// last stage of a layer's backward: qkv = x Wqkv^T + bqkv, plus the residual branch of LN1; result in sv.tH1
+int layer_backward_qkv(const Dims& d, const sskd_generic_layer_weights& lw, const sskd_generic_layer_grads& gw,
+                       const bf16_t* x_in, Saved& sv, bf16_t* dqkv, const bf16_t* dz1, hipStream_t st) {
+  const int H = d.H;
+  const int64_t M = d.M;
+  TRY(transpose2d(dqkv, M, 3 * H, 3 * H, sv.tA, M, st, gw.bqkv));  // [3H, M]; dbqkv on the way
+  TRY(transpose2d(x_in, M, H, H, sv.tB, M, st));          // [H, M]
+  TRY(gemm(sv.tA, M, sv.tB, M, gw.wqkv, H, 3 * H, H, (int)M, nullptr, true, true, st));
+  TRY(gemm(dqkv, 3 * H, static_cast<const bf16_t*>(lw.wqkv_t), 3 * H, sv.tH1, H, M, H, 3 * H, nullptr, false, false, st));
+  TRY(launch_add(sv.tH1, dz1, sv.tH1, M * H, st));        // + residual branch of LN1
+  return SSKD_OK;
+}
+
 // ---- backward of one layer: dx2 (gradient of the layer output) -> dx (gradient of its input) ----
 // dx2 is overwritten; the result is returned in sv.tH1.
 int layer_backward(const Dims& d, const sskd_generic_layer_weights& lw, const sskd_generic_layer_grads& gw,
                    const bf16_t* x_in, const int32_t* mask, const LayerSaved& ls, Saved& sv, bf16_t* dx2, hipStream_t st) {
-  (void)mask;
   const int H = d.H, S = d.S, DH = d.DH, NH = d.NH, F = d.F;
   const int64_t M = d.M;
   bf16_t* dz2 = sv.tH0;
   TRY(launch_ln_bwd(dx2, ls.z2, ls.mean2, ls.rstd2, lw.ln2_g, M, H, dz2, gw.ln2_g, gw.ln2_b, st));
   // y = hmid W2^T + b2
-  TRY(launch_colsum(dz2, M, H, H, gw.b2, st));
-  TRY(transpose2d(dz2, M, H, H, sv.tA, M, st));        // [H, M]
+  TRY(transpose2d(dz2, M, H, H, sv.tA, M, st, gw.b2));  // [H, M]; db2 = column sums on the way
   TRY(transpose2d(ls.hmid, M, F, F, sv.tB, M, st));    // [F, M]
   TRY(gemm(sv.tA, M, sv.tB, M, gw.w2, F, H, F, (int)M, nullptr, true, true, st));
   TRY(gemm(dz2, H, static_cast<const bf16_t*>(lw.w2_t), H, sv.tF0, F, M, F, H, nullptr, false, false, st));  // dhmid
   TRY(launch_gelu_bwd(ls.u, sv.tF0, sv.tF0, M * F, st));  // du (in place)
   // u = x1 W1^T + b1
-  TRY(launch_colsum(sv.tF0, M, F, F, gw.b1, st));
-  TRY(transpose2d(sv.tF0, M, F, F, sv.tA, M, st));     // [F, M]
+  TRY(transpose2d(sv.tF0, M, F, F, sv.tA, M, st, gw.b1));  // [F, M]; db1 on the way
   TRY(transpose2d(ls.x1, M, H, H, sv.tB, M, st));      // [H, M]
   TRY(gemm(sv.tA, M, sv.tB, M, gw.w1, H, F, H, (int)M, nullptr, true, true, st));
   bf16_t* dx1 = sv.tH1;
@@ -311,14 +343,18 @@ int layer_backward(const Dims& d, const sskd_generic_layer_weights& lw, const ss
   bf16_t* dz1 = sv.tH0;
   TRY(launch_ln_bwd(dx1, ls.z1, ls.mean1, ls.rstd1, lw.ln1_g, M, H, dz1, gw.ln1_g, gw.ln1_b, st));
   // attn_out = ctx Wo^T + bo
-  TRY(launch_colsum(dz1, M, H, H, gw.bo, st));
-  TRY(transpose2d(dz1, M, H, H, sv.tA, M, st));
+  TRY(transpose2d(dz1, M, H, H, sv.tA, M, st, gw.bo));
   TRY(transpose2d(ls.ctx, M, H, H, sv.tB, M, st));
   TRY(gemm(sv.tA, M, sv.tB, M, gw.wo, H, H, H, (int)M, nullptr, true, true, st));
   bf16_t* dctx = sv.tH2;
   TRY(gemm(dz1, H, static_cast<const bf16_t*>(lw.wo_t), H, dctx, H, M, H, H, nullptr, false, false, st));
 
   // ---- attention, per (batch row, head) ----
+  if (ls.lse) {
+    bf16_t* dqkv_f = sv.t3H;
+    TRY(launch_attention_bwd(ls.qkv, mask, ls.ctx, dctx, ls.lse, d.B, S, NH, DH, 1.0f / sqrtf((float)DH), dqkv_f, st));
+    return layer_backward_qkv(d, lw, gw, x_in, sv, dqkv_f, dz1, st);
+  }
   const int64_t bS3H = (int64_t)S * 3 * H, bPP = (int64_t)NH * S * S, hPP = (int64_t)S * S;
   // dP = dctx_bh V_bh^T
   GemmArgs g{};
@@ -432,14 +468,7 @@ int layer_backward(const Dims& d, const sskd_generic_layer_weights& lw, const ss
   gk.B = sv.tA;
   gk.C = dqkv + H;
   TRY(launch_gemm_nt(gk, st));
-  // qkv = x Wqkv^T + bqkv
-  TRY(launch_colsum(dqkv, M, 3 * H, 3 * H, gw.bqkv, st));
-  TRY(transpose2d(dqkv, M, 3 * H, 3 * H, sv.tA, M, st));  // [3H, M]
-  TRY(transpose2d(x_in, M, H, H, sv.tB, M, st));          // [H, M]
-  TRY(gemm(sv.tA, M, sv.tB, M, gw.wqkv, H, 3 * H, H, (int)M, nullptr, true, true, st));
-  TRY(gemm(dqkv, 3 * H, static_cast<const bf16_t*>(lw.wqkv_t), 3 * H, sv.tH1, H, M, H, 3 * H, nullptr, false, false, st));
-  TRY(launch_add(sv.tH1, dz1, sv.tH1, M * H, st));        // + residual branch of LN1
-  return SSKD_OK;
+  return layer_backward_qkv(d, lw, gw, x_in, sv, dqkv, dz1, st);
 }
 
 // Cross-encoder head input: hidden state of token 0 (<s>) of every sequence

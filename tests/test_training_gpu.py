@@ -71,7 +71,7 @@ def test_nt_gemm_matches_torch(gpu, native_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dims", ["small", "e5"])
+@pytest.mark.parametrize("dims", ["small", "e5", "heads64", "long", "unfused"])
 def test_encoder_gradients_match_oracle_autograd(gpu, dims):
     from semantic_search_kd_amd.training import TrainableEncoder
 
@@ -79,6 +79,18 @@ def test_encoder_gradients_match_oracle_autograd(gpu, dims):
         cfg = BertConfig(vocab_size=600, hidden_size=128, num_hidden_layers=2, num_attention_heads=4,
                          intermediate_size=512, max_position_embeddings=64)
         ids, mask = enc_oracle.synthetic_token_ids(5, 40, seed=31, vocab=600, lengths=[40, 33, 17, 8, 2])
+    elif dims == "heads64":  # head width 64: the other instantiation of the fused attention forward / backward
+        cfg = BertConfig(vocab_size=600, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                         intermediate_size=256, max_position_embeddings=128)
+        ids, mask = enc_oracle.synthetic_token_ids(4, 128, seed=35, vocab=600, lengths=[128, 97, 64, 3])
+    elif dims == "long":     # 256 tokens: all eight waves of the fused attention kernels own a tile
+        cfg = BertConfig(vocab_size=600, hidden_size=64, num_hidden_layers=1, num_attention_heads=2,
+                         intermediate_size=128, max_position_embeddings=256)
+        ids, mask = enc_oracle.synthetic_token_ids(3, 256, seed=36, vocab=600, lengths=[256, 200, 33])
+    elif dims == "unfused":  # S * head width beyond the fused backward's LDS budget: materialised-score path
+        cfg = BertConfig(vocab_size=600, hidden_size=128, num_hidden_layers=1, num_attention_heads=2,
+                         intermediate_size=256, max_position_embeddings=256)
+        ids, mask = enc_oracle.synthetic_token_ids(2, 160, seed=37, vocab=600, lengths=[160, 90])
     else:  # the e5-small-v2 architecture, 2 layers, reduced vocabulary (the embedding table is a gather)
         cfg = BertConfig(vocab_size=2000, num_hidden_layers=2)
         ids, mask = enc_oracle.synthetic_token_ids(6, 70, seed=33, vocab=2000, lengths=[70, 64, 33, 32, 9, 2])

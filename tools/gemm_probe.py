@@ -15,8 +15,10 @@ SHAPES = [  # (M, N, K, c_is_f32, accumulate, label)
     (65536, 384, 384, 0, 0, "student out-proj"),
     (65536, 1536, 384, 0, 0, "student FFN1"),
     (65536, 384, 1536, 0, 0, "student FFN2"),
-    (384, 384, 65536, 1, 1, "student dW (split-K)"),
+    (384, 384, 65536, 1, 1, "student dWo (split-K)"),
+    (1152, 384, 65536, 1, 1, "student dWqkv (split-K)"),
     (1536, 384, 65536, 1, 1, "student dW1 (split-K)"),
+    (384, 1536, 65536, 1, 1, "student dW2 (split-K)"),
     (32768, 3072, 1024, 0, 0, "teacher QKV"),
     (32768, 1024, 1024, 0, 0, "teacher out-proj"),
     (32768, 4096, 1024, 0, 0, "teacher FFN1"),
