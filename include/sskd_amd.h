@@ -133,8 +133,10 @@ int sskd_index_search_profiled(const float* d_tiled, int64_t n_rows,
  * neighbourhoods) are answered by the exact scan inside the same call, up to 1024 of them.
  * d_status (device int[2]): [0] = 0 ok, 1 = more than 1024 unproven queries - their output rows
  * hold (NaN, -2) and the caller must re-run sskd_index_search; [1] = queries that took the exact
- * fallback.  d_bf16: sskd_index_bf16_bytes(n_rows) bytes filled by sskd_index_make_bf16 from the
- * CURRENT tiled index (re-make it after sskd_index_add_rows). */
+ * fallback.  d_bf16: the screening sidecar, sskd_index_bf16_bytes(n_rows) bytes filled by
+ * sskd_index_make_bf16 from the CURRENT tiled index (re-make it after sskd_index_add_rows): the bf16
+ * tiles (768 B per row), max |row|^2, and the fp32 rows row-major (1536 B per row: the re-scoring
+ * gathers read whole cache lines from it). */
 size_t sskd_index_bf16_bytes(int64_t n_rows);
 int sskd_index_make_bf16(const float* d_tiled, int64_t n_rows, void* d_bf16, void* stream);
 size_t sskd_index_search_screened_workspace_bytes(int64_t n_rows, int nq, int k);

@@ -90,7 +90,7 @@ class FAISSIndexBuilder:
         # the exact scan (proved error band + exact re-scoring + exact fallback), several times faster.
         # ``screening = False`` forces the plain exact scan.
         self.screening = True
-        self._bf16: Optional[torch.Tensor] = None      # bf16 copy of the tiles (+ max row norm), made lazily
+        self._bf16: Optional[torch.Tensor] = None      # screening sidecar (bf16 tiles, max row norm, row-major fp32 rows), made lazily
         self._bf16_rows = -1
         self.last_status: Optional[torch.Tensor] = None  # device int32[2] of the last screened search
         self.index: Optional[IndexHandle] = None
