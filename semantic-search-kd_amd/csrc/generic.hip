@@ -172,6 +172,122 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------- //
+// NT GEMM, 256 x 256 block tile (large unbatched products: M, N multiples of 256, K of 64, bf16 out).
+// 8 waves as 2 (M) x 4 (N), each 128 x 64 = 8 x 4 tiles of v_mfma_f32_16x16x32_bf16 (128 accumulator
+// registers).  Operand tiles go global -> LDS directly (global_load_lds, 16 B per lane, no staging
+// registers); two 64 KiB stages; ONE barrier per 64-deep K tile: wait for tile t, barrier, request tile
+// t + 1 into the other stage, multiply tile t.  The LDS image of a tile is row-linear (a wave's DMA
+// writes 1 KiB = 8 rows of 128 B); bank conflicts are avoided by swizzling on the SOURCE side: LDS chunk c
+// of row r holds global chunk c ^ (r & 7), and the fragment reads apply the same XOR.
+// One workgroup per CU (128 KiB of LDS): against the 128 x 128 kernel above, 4x the flops per operand byte
+// staged and half the barriers per flop.
+// ------------------------------------------------------------------------- //
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ inline void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmArgs p) {
+  constexpr int BK = 64;
+  constexpr int STAGE = 2 * 256 * BK;  // bf16 elements of one stage: A tile then B tile (64 KiB)
+  extern __shared__ __attribute__((aligned(16))) unsigned char g256_lds[];
+  bf16_t* const lds = reinterpret_cast<bf16_t*>(g256_lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int m0 = blockIdx.y * 256, n0 = blockIdx.x * 256;
+  const int nk = p.K / BK;
+
+  // DMA geometry: instruction i of wave w fills LDS bytes [(8 i + w) KiB, + 1 KiB) of a tile = rows 8 (8 i + w) .. + 7
+  const int drow = lane >> 3, dchunk = (lane & 7) ^ drow;  // (8 (8 i + w) + drow) & 7 == drow
+  const bf16_t* ga[4];
+  const bf16_t* gb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 8 * (8 * i + wave) + drow;
+    ga[i] = p.A + (int64_t)(m0 + row) * p.lda + dchunk * 8;
+    gb[i] = p.B + (int64_t)(n0 + row) * p.ldb + dchunk * 8;
+  }
+  auto request = [&](int stage, int kt) {
+    bf16_t* const sa = lds + stage * STAGE;
+    bf16_t* const sb = sa + 256 * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(ga[i] + kt * BK, sa + (8 * i + wave) * 512);
+      glds16(gb[i] + kt * BK, sb + (8 * i + wave) * 512);
+    }
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment reads: lane -> row (lane & 15) of a 16-row block, k chunk 4 kk + (lane >> 4), XOR-swizzled by row & 7
+  const int fr = lane & 15, fq = lane >> 4;
+  request(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of tile kt have landed
+    __syncthreads();                     // everybody's have; everybody is done with the other stage
+    if (kt + 1 < nk) request((kt + 1) & 1, kt + 1);
+    const bf16_t* const sa = lds + (kt & 1) * STAGE + (wr * 128) * BK;
+    const bf16_t* const sb = lds + (kt & 1) * STAGE + 256 * BK + (wc * 64) * BK;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 a[8], b[4];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = i * 16 + fr;
+        a[i] = *reinterpret_cast<const bf16x8*>(sa + row * BK + (((4 * kk + fq) ^ (row & 7)) << 3));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = j * 16 + fr;
+        b[j] = *reinterpret_cast<const bf16x8*>(sb + row * BK + (((4 * kk + fq) ^ (row & 7)) << 3));
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // epilogue: acc[i][j][e] = C[m0 + 128 wr + 16 i + 4 fq + e][n0 + 64 wc + 16 j + fr]; each wave turns 16 rows x 64
+  // columns at a time through its own 2.25 KiB of LDS into 16-byte row segments
+  __syncthreads();  // all fragment reads done: the stages are free
+  constexpr int LDW = 64 + 8;
+  bf16_t* const wt = lds + wave * (16 * LDW);
+  bf16_t* const Cg = static_cast<bf16_t*>(p.C);
+  float bias[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bias[j] = p.bias ? p.bias[n0 + wc * 64 + j * 16 + fr] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = p.alpha * acc[i][j][e] + bias[j];
+        if (p.act == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+        wt[(4 * fq + e) * LDW + j * 16 + fr] = (bf16_t)v;
+      }
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's own LDS writes (wave-private region)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int row = (lane >> 3) + 8 * h2, c8 = (lane & 7) * 8;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(wt + row * LDW + c8);
+      *reinterpret_cast<u32x4*>(Cg + (int64_t)(m0 + wr * 128 + i * 16 + row) * p.ldc + n0 + wc * 64 + c8) = v;
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ------------------------------------------------------------------------- //
 // Fused inference attention (teacher cross-encoder): one workgroup = one (batch row, head) and up to 8
 // query tiles of 32 (one per wave); K and V of the head are staged once in LDS in MFMA fragment order.
 //   S^T = K Q^T      A = K fragments [key, dim] (16 contiguous bytes of a qkv row), B = Q^T fragments
@@ -1046,6 +1162,18 @@ int launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
                "gemm_nt: split-K needs an unbatched fp32 accumulating output without bias");
   const dim3 grid((unsigned)sskd::ceil_div(a.N, 128), (unsigned)sskd::ceil_div(a.M, 128),
                   (unsigned)(a.split_k > 1 ? a.split_k : a.batch1 * a.batch2));
+  const bool big = a.batch1 * a.batch2 == 1 && a.split_k <= 1 && !a.c_is_f32 && a.M % 256 == 0 && a.N % 256 == 0 &&
+                   a.K % 64 == 0 && a.M >= 1024 && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldc % 8 == 0 &&
+                   (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(a.C) & 15) == 0;
+#ifndef SSKD_NO_GEMM256
+  if (big) {
+    constexpr int lds256 = 2 * 2 * 256 * 64 * 2;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
+    hipLaunchKernelGGL(gemm_nt256_kernel, dim3((unsigned)(a.N / 256), (unsigned)(a.M / 256), 1), dim3(512), lds256, st, a);
+    return sskd::check_launch("gemm_nt256_kernel");
+  }
+#endif
   if (a.K % 64 == 0) hipLaunchKernelGGL(gemm_nt_kernel<64>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(gemm_nt_kernel<32>, grid, dim3(256), 0, st, a);
   return sskd::check_launch("gemm_nt_kernel");
