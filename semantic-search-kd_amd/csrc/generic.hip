@@ -189,42 +189,48 @@ __device__ inline void glds16(const void* g, void* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+template <int BN>   // 256, or 128 for outputs whose width is a multiple of 128 only (the 384-wide student)
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmArgs p) {
   constexpr int BK = 64;
-  constexpr int STAGE = 2 * 256 * BK;  // bf16 elements of one stage: A tile then B tile (64 KiB)
+  constexpr int NREP = BN / 64;              // 16-column MFMA tiles per wave (4 waves across N)
+  constexpr int STAGE = (256 + BN) * BK;     // bf16 elements of one stage: A tile then B tile
   extern __shared__ __attribute__((aligned(16))) unsigned char g256_lds[];
   bf16_t* const lds = reinterpret_cast<bf16_t*>(g256_lds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-  const int m0 = blockIdx.y * 256, n0 = blockIdx.x * 256;
+  // workgroups are dealt to the 8 XCDs round-robin.  For narrow outputs (<= 12 tiles across N) give each XCD a
+  // contiguous run of tiles (N fastest), so the A row panel and the B column panels it re-reads stay in ITS L2
+  // (bijective for any grid size): +4..40 % on the 384- to 3072-wide products; wide outputs (8192: 32 tiles
+  // across) lose 7 % to it and keep the dealt order.
+  const int tiles_n = p.N / BN;
+  const int nwg = gridDim.x, xcd = blockIdx.x & 7;
+  const int bid = tiles_n <= 12 ? xcd * (nwg >> 3) + min(xcd, nwg & 7) + (blockIdx.x >> 3) : (int)blockIdx.x;
+  const int m0 = (bid / tiles_n) * 256, n0 = (bid % tiles_n) * BN;
   const int nk = p.K / BK;
 
   // DMA geometry: instruction i of wave w fills LDS bytes [(8 i + w) KiB, + 1 KiB) of a tile = rows 8 (8 i + w) .. + 7
   const int drow = lane >> 3, dchunk = (lane & 7) ^ drow;  // (8 (8 i + w) + drow) & 7 == drow
   const bf16_t* ga[4];
-  const bf16_t* gb[4];
+  const bf16_t* gb[NREP];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = 8 * (8 * i + wave) + drow;
-    ga[i] = p.A + (int64_t)(m0 + row) * p.lda + dchunk * 8;
-    gb[i] = p.B + (int64_t)(n0 + row) * p.ldb + dchunk * 8;
-  }
+  for (int i = 0; i < 4; ++i) ga[i] = p.A + (int64_t)(m0 + 8 * (8 * i + wave) + drow) * p.lda + dchunk * 8;
+#pragma unroll
+  for (int i = 0; i < NREP; ++i) gb[i] = p.B + (int64_t)(n0 + 8 * (8 * i + wave) + drow) * p.ldb + dchunk * 8;
   auto request = [&](int stage, int kt) {
     bf16_t* const sa = lds + stage * STAGE;
     bf16_t* const sb = sa + 256 * BK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      glds16(ga[i] + kt * BK, sa + (8 * i + wave) * 512);
-      glds16(gb[i] + kt * BK, sb + (8 * i + wave) * 512);
-    }
+    for (int i = 0; i < 4; ++i) glds16(ga[i] + kt * BK, sa + (8 * i + wave) * 512);
+#pragma unroll
+    for (int i = 0; i < NREP; ++i) glds16(gb[i] + kt * BK, sb + (8 * i + wave) * 512);
   };
 
-  f32x4 acc[8][4];
+  f32x4 acc[8][NREP];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // fragment reads: lane -> row (lane & 15) of a 16-row block, k chunk 4 kk + (lane >> 4), XOR-swizzled by row & 7
   const int fr = lane & 15, fq = lane >> 4;
@@ -234,40 +240,42 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmArgs p) {
     __syncthreads();                     // everybody's have; everybody is done with the other stage
     if (kt + 1 < nk) request((kt + 1) & 1, kt + 1);
     const bf16_t* const sa = lds + (kt & 1) * STAGE + (wr * 128) * BK;
-    const bf16_t* const sb = lds + (kt & 1) * STAGE + 256 * BK + (wc * 64) * BK;
+    const bf16_t* const sb = lds + (kt & 1) * STAGE + 256 * BK + (wc * (BN / 4)) * BK;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 a[8], b[4];
+      bf16x8 a[8], b[NREP];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int row = i * 16 + fr;
         a[i] = *reinterpret_cast<const bf16x8*>(sa + row * BK + (((4 * kk + fq) ^ (row & 7)) << 3));
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NREP; ++j) {
         const int row = j * 16 + fr;
         b[j] = *reinterpret_cast<const bf16x8*>(sb + row * BK + (((4 * kk + fq) ^ (row & 7)) << 3));
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NREP; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
 
-  // epilogue: acc[i][j][e] = C[m0 + 128 wr + 16 i + 4 fq + e][n0 + 64 wc + 16 j + fr]; each wave turns 16 rows x 64
-  // columns at a time through its own 2.25 KiB of LDS into 16-byte row segments
+  // epilogue: acc[i][j][e] = C[m0 + 128 wr + 16 i + 4 fq + e][n0 + (BN / 4) wc + 16 j + fr]; each wave turns 16 rows at a
+  // time through its own slice of LDS into 16-byte row segments
   __syncthreads();  // all fragment reads done: the stages are free
-  constexpr int LDW = 64 + 8;
+  constexpr int WN = BN / 4;     // columns per wave
+  constexpr int LDW = WN + 8;
   bf16_t* const wt = lds + wave * (16 * LDW);
   bf16_t* const Cg = static_cast<bf16_t*>(p.C);
-  float bias[4];
+  float bias[NREP];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) bias[j] = p.bias ? p.bias[n0 + wc * 64 + j * 16 + fr] : 0.f;
+  for (int j = 0; j < NREP; ++j) bias[j] = p.bias ? p.bias[n0 + wc * WN + j * 16 + fr] : 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NREP; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float v = p.alpha * acc[i][j][e] + bias[j];
@@ -276,11 +284,12 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmArgs p) {
       }
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's own LDS writes (wave-private region)
     __builtin_amdgcn_wave_barrier();
+    constexpr int CPR = WN / 8;          // 16-byte segments per row: 8 or 4
 #pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {
-      const int row = (lane >> 3) + 8 * h2, c8 = (lane & 7) * 8;
+    for (int h2 = 0; h2 < 16 * CPR / 64; ++h2) {
+      const int seg = lane + 64 * h2, row = seg / CPR, c8 = (seg % CPR) * 8;
       const u32x4 v = *reinterpret_cast<const u32x4*>(wt + row * LDW + c8);
-      *reinterpret_cast<u32x4*>(Cg + (int64_t)(m0 + wr * 128 + i * 16 + row) * p.ldc + n0 + wc * 64 + c8) = v;
+      *reinterpret_cast<u32x4*>(Cg + (int64_t)(m0 + wr * 128 + i * 16 + row) * p.ldc + n0 + wc * WN + c8) = v;
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
@@ -1162,15 +1171,19 @@ int launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
                "gemm_nt: split-K needs an unbatched fp32 accumulating output without bias");
   const dim3 grid((unsigned)sskd::ceil_div(a.N, 128), (unsigned)sskd::ceil_div(a.M, 128),
                   (unsigned)(a.split_k > 1 ? a.split_k : a.batch1 * a.batch2));
-  const bool big = a.batch1 * a.batch2 == 1 && a.split_k <= 1 && !a.c_is_f32 && a.M % 256 == 0 && a.N % 256 == 0 &&
+  const bool big = a.batch1 * a.batch2 == 1 && a.split_k <= 1 && !a.c_is_f32 && a.M % 256 == 0 && a.N % 128 == 0 &&
                    a.K % 64 == 0 && a.M >= 1024 && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldc % 8 == 0 &&
                    (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 15) == 0 &&
                    (reinterpret_cast<uintptr_t>(a.C) & 15) == 0;
 #ifndef SSKD_NO_GEMM256
   if (big) {
-    constexpr int lds256 = 2 * 2 * 256 * 64 * 2;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
-    hipLaunchKernelGGL(gemm_nt256_kernel, dim3((unsigned)(a.N / 256), (unsigned)(a.M / 256), 1), dim3(512), lds256, st, a);
+    auto go = [&](auto kern, int bn) {
+      const int lds256 = 2 * (256 + bn) * 64 * 2;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
+      hipLaunchKernelGGL(kern, dim3((unsigned)((a.N / bn) * (a.M / 256))), dim3(512), lds256, st, a);
+    };
+    if (a.N % 256 == 0) go(gemm_nt256_kernel<256>, 256);
+    else go(gemm_nt256_kernel<128>, 128);
     return sskd::check_launch("gemm_nt256_kernel");
   }
 #endif

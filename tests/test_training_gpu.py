@@ -59,7 +59,8 @@ def test_nt_gemm_matches_torch(gpu, native_lib):
     for M, N, K, f32, acc in ((128, 128, 64, 0, 0), (300, 130, 96, 1, 0), (1000, 384, 384, 0, 0), (77, 1536, 32, 1, 1),
                                (384, 1152, 4096, 1, 1), (5, 3, 32, 0, 0),
                                # the 256 x 256 global-to-LDS kernel (M, N multiples of 256, K of 64, bf16 out)
-                               (1024, 256, 64, 0, 0), (2048, 768, 1024, 0, 0), (1280, 512, 192, 0, 0)):
+                               (1024, 256, 64, 0, 0), (2048, 768, 1024, 0, 0), (1280, 512, 192, 0, 0), (1536, 384, 384, 0, 0),
+                               (4096, 1152, 128, 0, 0), (2304, 1280, 64, 0, 0)):
         a = torch.randn((M, K), generator=g, device="cuda").to(torch.bfloat16)
         b = torch.randn((N, K), generator=g, device="cuda").to(torch.bfloat16)
         bias = torch.randn(N, generator=g, device="cuda")
