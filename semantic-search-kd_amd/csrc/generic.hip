@@ -183,6 +183,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
 // staged and half the barriers per flop.
 // ------------------------------------------------------------------------- //
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int GEMM256_CUS = 256;  // persistent grid: one workgroup per CU of an MI355X
 
 __device__ inline void glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -194,105 +195,115 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmArgs p) {
   constexpr int BK = 64;
   constexpr int NREP = BN / 64;              // 16-column MFMA tiles per wave (4 waves across N)
   constexpr int STAGE = (256 + BN) * BK;     // bf16 elements of one stage: A tile then B tile
+  constexpr int WN = BN / 4;                 // output columns per wave
+  constexpr int LDW = WN + 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char g256_lds[];
   bf16_t* const lds = reinterpret_cast<bf16_t*>(g256_lds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-  // workgroups are dealt to the 8 XCDs round-robin.  For narrow outputs (<= 12 tiles across N) give each XCD a
-  // contiguous run of tiles (N fastest), so the A row panel and the B column panels it re-reads stay in ITS L2
-  // (bijective for any grid size): +4..40 % on the 384- to 3072-wide products; wide outputs (8192: 32 tiles
-  // across) lose 7 % to it and keep the dealt order.
+  bf16_t* const wt = lds + 2 * STAGE + wave * (16 * LDW);  // epilogue slice of this wave, outside the stages
   const int tiles_n = p.N / BN;
-  const int nwg = gridDim.x, xcd = blockIdx.x & 7;
-  const int bid = tiles_n <= 12 ? xcd * (nwg >> 3) + min(xcd, nwg & 7) + (blockIdx.x >> 3) : (int)blockIdx.x;
-  const int m0 = (bid / tiles_n) * 256, n0 = (bid % tiles_n) * BN;
+  const int total = tiles_n * (p.M / 256);
   const int nk = p.K / BK;
-
+  // PERSISTENT workgroups (one per CU): workgroup b multiplies output tiles b, b + grid, ...; the first K tile of
+  // the next output tile is requested before the current one's epilogue, so the DMA pipeline never restarts
+  // (short K: 384 is 6 K tiles per output tile).
+  // Tile order: workgroups are dealt to the 8 XCDs round-robin (grid is a multiple of 8 or the whole problem).  For
+  // narrow outputs (<= 12 tiles across N) an XCD gets a contiguous run of tiles (N fastest), so the A row panel and the
+  // B column panels it re-reads stay in ITS L2 (bijective): +4..40 % on the 384- to 3072-wide products; wide outputs
+  // (8192: 32 tiles across) lose 7 % to it and keep the dealt order.
+  auto coords = [&](int v, int& m0, int& n0) {
+    const int xcd = v & 7;
+    const int t = tiles_n <= 12 ? xcd * (total >> 3) + min(xcd, total & 7) + (v >> 3) : v;
+    m0 = (t / tiles_n) * 256;
+    n0 = (t % tiles_n) * BN;
+  };
   // DMA geometry: instruction i of wave w fills LDS bytes [(8 i + w) KiB, + 1 KiB) of a tile = rows 8 (8 i + w) .. + 7
   const int drow = lane >> 3, dchunk = (lane & 7) ^ drow;  // (8 (8 i + w) + drow) & 7 == drow
-  const bf16_t* ga[4];
-  const bf16_t* gb[NREP];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) ga[i] = p.A + (int64_t)(m0 + 8 * (8 * i + wave) + drow) * p.lda + dchunk * 8;
-#pragma unroll
-  for (int i = 0; i < NREP; ++i) gb[i] = p.B + (int64_t)(n0 + 8 * (8 * i + wave) + drow) * p.ldb + dchunk * 8;
-  auto request = [&](int stage, int kt) {
+  auto request = [&](int stage, int m0, int n0, int kt) {
     bf16_t* const sa = lds + stage * STAGE;
     bf16_t* const sb = sa + 256 * BK;
+    const bf16_t* ga = p.A + (int64_t)(m0 + 8 * wave + drow) * p.lda + dchunk * 8 + kt * BK;
+    const bf16_t* gb = p.B + (int64_t)(n0 + 8 * wave + drow) * p.ldb + dchunk * 8 + kt * BK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(ga[i] + kt * BK, sa + (8 * i + wave) * 512);
+    for (int i = 0; i < 4; ++i) glds16(ga + (int64_t)(64 * i) * p.lda, sa + (8 * i + wave) * 512);
 #pragma unroll
-    for (int i = 0; i < NREP; ++i) glds16(gb[i] + kt * BK, sb + (8 * i + wave) * 512);
+    for (int i = 0; i < NREP; ++i) glds16(gb + (int64_t)(64 * i) * p.ldb, sb + (8 * i + wave) * 512);
   };
 
   f32x4 acc[8][NREP];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
   // fragment reads: lane -> row (lane & 15) of a 16-row block, k chunk 4 kk + (lane >> 4), XOR-swizzled by row & 7
   const int fr = lane & 15, fq = lane >> 4;
-  request(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of tile kt have landed
-    __syncthreads();                     // everybody's have; everybody is done with the other stage
-    if (kt + 1 < nk) request((kt + 1) & 1, kt + 1);
-    const bf16_t* const sa = lds + (kt & 1) * STAGE + (wr * 128) * BK;
-    const bf16_t* const sb = lds + (kt & 1) * STAGE + 256 * BK + (wc * (BN / 4)) * BK;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 a[8], b[NREP];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int row = i * 16 + fr;
-        a[i] = *reinterpret_cast<const bf16x8*>(sa + row * BK + (((4 * kk + fq) ^ (row & 7)) << 3));
-      }
-#pragma unroll
-      for (int j = 0; j < NREP; ++j) {
-        const int row = j * 16 + fr;
-        b[j] = *reinterpret_cast<const bf16x8*>(sb + row * BK + (((4 * kk + fq) ^ (row & 7)) << 3));
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < NREP; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-  }
-
-  // epilogue: acc[i][j][e] = C[m0 + 128 wr + 16 i + 4 fq + e][n0 + (BN / 4) wc + 16 j + fr]; each wave turns 16 rows at a
-  // time through its own slice of LDS into 16-byte row segments
-  __syncthreads();  // all fragment reads done: the stages are free
-  constexpr int WN = BN / 4;     // columns per wave
-  constexpr int LDW = WN + 8;
-  bf16_t* const wt = lds + wave * (16 * LDW);
   bf16_t* const Cg = static_cast<bf16_t*>(p.C);
-  float bias[NREP];
+  int v = blockIdx.x, m0, n0, step = 0;
+  if (v >= total) return;
+  coords(v, m0, n0);
+  request(0, m0, n0, 0);
+  for (; v < total; v += gridDim.x) {
 #pragma unroll
-  for (int j = 0; j < NREP; ++j) bias[j] = p.bias ? p.bias[n0 + wc * WN + j * 16 + fr] : 0.f;
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+      for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int m1 = 0, n1 = 0;
+    const bool more_tiles = v + (int)gridDim.x < total;
+    if (more_tiles) coords(v + gridDim.x, m1, n1);
+    for (int kt = 0; kt < nk; ++kt, ++step) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of the current K tile have landed
+      __syncthreads();                     // everybody's have; everybody is done with the other stage
+      if (kt + 1 < nk) request((step + 1) & 1, m0, n0, kt + 1);
+      else if (more_tiles) request((step + 1) & 1, m1, n1, 0);
+      const bf16_t* const sa = lds + (step & 1) * STAGE + (wr * 128) * BK;
+      const bf16_t* const sb = lds + (step & 1) * STAGE + 256 * BK + (wc * WN) * BK;
 #pragma unroll
-    for (int j = 0; j < NREP; ++j)
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 a[8], b[NREP];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float v = p.alpha * acc[i][j][e] + bias[j];
-        if (p.act == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-        wt[(4 * fq + e) * LDW + j * 16 + fr] = (bf16_t)v;
+        for (int i = 0; i < 8; ++i) {
+          const int row = i * 16 + fr;
+          a[i] = *reinterpret_cast<const bf16x8*>(sa + row * BK + (((4 * kk + fq) ^ (row & 7)) << 3));
+        }
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) {
+          const int row = j * 16 + fr;
+          b[j] = *reinterpret_cast<const bf16x8*>(sb + row * BK + (((4 * kk + fq) ^ (row & 7)) << 3));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < NREP; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
       }
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's own LDS writes (wave-private region)
-    __builtin_amdgcn_wave_barrier();
-    constexpr int CPR = WN / 8;          // 16-byte segments per row: 8 or 4
-#pragma unroll
-    for (int h2 = 0; h2 < 16 * CPR / 64; ++h2) {
-      const int seg = lane + 64 * h2, row = seg / CPR, c8 = (seg % CPR) * 8;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(wt + row * LDW + c8);
-      *reinterpret_cast<u32x4*>(Cg + (int64_t)(m0 + wr * 128 + i * 16 + row) * p.ldc + n0 + wc * WN + c8) = v;
     }
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();
+    // epilogue: acc[i][j][e] = C[m0 + 128 wr + 16 i + 4 fq + e][n0 + WN wc + 16 j + fr]; each wave turns 16 rows at a
+    // time through its own slice of LDS into 16-byte row segments (the next tile's DMA is already in flight)
+    float bias[NREP];
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) bias[j] = p.bias ? p.bias[n0 + wc * WN + j * 16 + fr] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < NREP; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = p.alpha * acc[i][j][e] + bias[j];
+          if (p.act == 1) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+          wt[(4 * fq + e) * LDW + j * 16 + fr] = (bf16_t)x;
+        }
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's own LDS writes (wave-private slice)
+      __builtin_amdgcn_wave_barrier();
+      constexpr int CPR = WN / 8;          // 16-byte segments per row: 8 or 4
+#pragma unroll
+      for (int h2 = 0; h2 < 16 * CPR / 64; ++h2) {
+        const int seg = lane + 64 * h2, row = seg / CPR, c8 = (seg % CPR) * 8;
+        const u32x4 val = *reinterpret_cast<const u32x4*>(wt + row * LDW + c8);
+        *reinterpret_cast<u32x4*>(Cg + (int64_t)(m0 + wr * 128 + i * 16 + row) * p.ldc + n0 + wc * WN + c8) = val;
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_wave_barrier();
+    }
+    m0 = m1;
+    n0 = n1;
   }
 }
 
@@ -1178,9 +1189,10 @@ int launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
 #ifndef SSKD_NO_GEMM256
   if (big) {
     auto go = [&](auto kern, int bn) {
-      const int lds256 = 2 * (256 + bn) * 64 * 2;
+      const int lds256 = 2 * (256 + bn) * 64 * 2 + 8 * 16 * (bn / 4 + 8) * 2;  // two stages + the waves' epilogue slices
+      const int tiles = (a.N / bn) * (a.M / 256);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
-      hipLaunchKernelGGL(kern, dim3((unsigned)((a.N / bn) * (a.M / 256))), dim3(512), lds256, st, a);
+      hipLaunchKernelGGL(kern, dim3((unsigned)(tiles < GEMM256_CUS ? tiles : GEMM256_CUS)), dim3(512), lds256, st, a);
     };
     if (a.N % 256 == 0) go(gemm_nt256_kernel<256>, 256);
     else go(gemm_nt256_kernel<128>, 128);
