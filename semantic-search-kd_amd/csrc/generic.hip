@@ -255,6 +255,33 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmArgs p) {
       else if (more_tiles) request((step + 1) & 1, m1, n1, 0);
       const bf16_t* const sa = lds + (step & 1) * STAGE + (wr * 128) * BK;
       const bf16_t* const sb = lds + (step & 1) * STAGE + 256 * BK + (wc * WN) * BK;
+#ifndef SSKD_GEMM256_FRAGS_PER_STEP
+      // both k-steps' fragments requested up front (the second step's reads land behind the first step's MFMAs) and the
+      // MFMA block at raised priority: +5..10 % on deep-K shapes (8192^3: 1 287 -> 1 359 TFLOP/s), -2 % on K = 384
+      bf16x8 a[2][8], b[2][NREP];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int row = i * 16 + fr;
+          a[kk][i] = *reinterpret_cast<const bf16x8*>(sa + row * BK + (((4 * kk + fq) ^ (row & 7)) << 3));
+        }
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) {
+          const int row = j * 16 + fr;
+          b[kk][j] = *reinterpret_cast<const bf16x8*>(sb + row * BK + (((4 * kk + fq) ^ (row & 7)) << 3));
+        }
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < NREP; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+#else
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         bf16x8 a[8], b[NREP];
@@ -268,12 +295,19 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmArgs p) {
           const int row = j * 16 + fr;
           b[j] = *reinterpret_cast<const bf16x8*>(sb + row * BK + (((4 * kk + fq) ^ (row & 7)) << 3));
         }
+#ifdef SSKD_GEMM256_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
           for (int j = 0; j < NREP; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+#ifdef SSKD_GEMM256_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
       }
+#endif
     }
     // epilogue: acc[i][j][e] = C[m0 + 128 wr + 16 i + 4 fq + e][n0 + WN wc + 16 j + fr]; each wave turns 16 rows at a
     // time through its own slice of LDS into 16-byte row segments (the next tile's DMA is already in flight)
