@@ -62,9 +62,9 @@ def _worker(rank, world, port, n, nq, k, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,nq,k", [(1000, 17, 10), (5, 3, 10)])
-def test_sharded_search_equals_unsharded(tmp_path, n, nq, k):
-    world = 2
+@pytest.mark.parametrize("n,nq,k,world", [(1000, 17, 10, 2), (5, 3, 10, 2), (1003, 9, 10, 4), (3, 2, 5, 4)])
+def test_sharded_search_equals_unsharded(tmp_path, n, nq, k, world):
+    """world 4 with a ragged last shard, and more ranks than rows (empty shards) as well"""
     mp.spawn(_worker, args=(world, _free_port(), n, nq, k, str(tmp_path)), nprocs=world, join=True)
     corpus = oracle.seeded_unit_rows(n, 384, 1234)
     queries = oracle.seeded_unit_rows(nq, 384, 4321)
