@@ -404,6 +404,10 @@ int sskd_teacher_score(const sskd_generic_config* cfg, const sskd_generic_weight
  * product of the generic path goes through (test hook; K % 32 == 0). */
 int sskd_gemm_nt_bf16(const void* d_a, const void* d_b, void* d_c, const float* d_bias, int M, int N, int K,
                       int c_is_f32, int accumulate, void* stream);
+/* C[M, N] (fp32) += A[T, M]^T . B[T, N]: the weight-gradient product of the training step with the token
+ * dimension as the row of both bf16 operands (test hook; M % 384 == 0, N % 128 == 0, T % 64 == 0, else
+ * SSKD_ERR_UNSUPPORTED: the step then transposes and uses the NT kernel). */
+int sskd_gemm_tn_bf16(const void* d_a, const void* d_b, float* d_c, int64_t T, int M, int N, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Host WordPiece tokenizer (uncased BERT): replaces the `tokenizers` call inside

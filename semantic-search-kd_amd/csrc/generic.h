@@ -30,6 +30,13 @@ struct GemmArgs {
 
 int launch_gemm_nt(const GemmArgs& a, hipStream_t st);
 
+// Weight-gradient product with NO operand transposes: C[M, N] (fp32) += A[T, M]^T B[T, N], the reduction (token)
+// dimension being the ROW of both row-major operands.  T is cut over workgroups, partial tiles meet through fp32
+// atomics.  Served when M % 384 == 0, N % 128 == 0, T % 64 == 0 (gemm_tn_supported): the student's shapes.
+bool gemm_tn_supported(int64_t T, int M, int N, int64_t lda, int64_t ldb);
+int launch_gemm_tn(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, float* C, int64_t ldc, int64_t T, int M,
+                   int N, hipStream_t st);
+
 // out[C, R] = in[R, C]^T, batched like the GEMM (element strides).
 struct TransposeArgs {
   const bf16_t* in;

@@ -342,6 +342,124 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------- //
+// TN product for weight gradients: C[M, N] += A[T, M]^T B[T, N] (fp32 atomics), 384 x 128 output tile.
+// Both operands are row-major with the REDUCTION index (token) as the row, so a K tile of 64 tokens is DMA'd
+// as it lies in memory ([token][feature], global_load_lds) and the MFMA fragments - 8 consecutive tokens of one
+// feature per lane - are gathered by ds_read_b64_tr_b16, gfx950's transposing LDS read (a 16-lane group reads
+// 4 token rows x 16 feature columns and each lane receives one column).  That removes the two operand transposes
+// per product the NT kernel needs.  LDS chunk c of token row r holds global chunk c ^ swz(r),
+// swz(r) = 2 (r & 3) ^ 8 ((r >> 3) & 1): the 4 rows of a read and the two groups of a 32-lane half land on
+// different banks.  8 waves as 2 (M) x 4 (N), each 192 x 32 = 12 x 2 tiles of v_mfma_f32_16x16x32_bf16.
+// grid = (output tiles, K slices).
+// ------------------------------------------------------------------------- //
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+struct GemmTnArgs {
+  const bf16_t* A;
+  const bf16_t* B;
+  float* C;
+  int64_t lda, ldb, ldc, T;
+  int M, N;
+  int k_per;   // K tiles (of 64 tokens) per slice
+};
+
+__device__ inline int tn_swz(int row) { return (2 * (row & 3)) ^ (8 * ((row >> 3) & 1)); }
+
+__global__ __launch_bounds__(512) void gemm_tn384_kernel(GemmTnArgs p) {
+  constexpr int BK = 64, TM = 384, TN = 128;
+  constexpr int CA = TM / 8, CB = TN / 8;        // 16-byte chunks per token row: 48, 16
+  constexpr int STAGE = (TM + TN) * BK;          // bf16 elements per stage (64 KiB)
+  extern __shared__ __attribute__((aligned(16))) unsigned char gtn_lds[];
+  bf16_t* const lds = reinterpret_cast<bf16_t*>(gtn_lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n = p.N / TN;
+  const int m0 = (blockIdx.x / tiles_n) * TM, n0 = (blockIdx.x % tiles_n) * TN;
+  const int nk_all = (int)(p.T / BK);
+  const int kt0 = blockIdx.y * p.k_per;
+  const int nk = min(p.k_per, nk_all - kt0);
+  if (nk <= 0) return;
+
+  // DMA: the image of a K tile is [64 tokens][chunks] linear; wave-instruction (8 i + w) writes chunks 64 (8 i + w) .. + 63
+  int a_off[6], b_off[2];   // element offsets of this lane's source chunk, relative to the K tile's first token row
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int L = (8 * i + wave) * 64 + lane, row = L / CA, c = L - row * CA;
+    a_off[i] = row * (int)p.lda + m0 + ((c ^ tn_swz(row)) << 3);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int L = (8 * i + wave) * 64 + lane, row = L / CB, c = L - row * CB;
+    b_off[i] = row * (int)p.ldb + n0 + ((c ^ tn_swz(row)) << 3);
+  }
+  auto request = [&](int stage, int kt) {
+    bf16_t* const sa = lds + stage * STAGE;
+    bf16_t* const sb = sa + TM * BK;
+    const bf16_t* ga = p.A + (int64_t)(kt0 + kt) * BK * p.lda;
+    const bf16_t* gb = p.B + (int64_t)(kt0 + kt) * BK * p.ldb;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) glds16(ga + a_off[i], sa + (8 * i + wave) * 512);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(gb + b_off[i], sb + (8 * i + wave) * 512);
+  };
+
+  f32x4 acc[12][2];
+#pragma unroll
+  for (int i = 0; i < 12; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // transposed fragment reads: lane 4 q + pp of a 16-lane group supplies the address of token row q, columns 4 pp .. + 3
+  const int fr = lane & 15, fq = lane >> 4, q = fr >> 2, pp = fr & 3;
+  request(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    if (kt + 1 < nk) request((kt + 1) & 1, kt + 1);
+    const bf16_t* const sa = lds + (kt & 1) * STAGE;
+    const bf16_t* const sb = sa + TM * BK;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      s16x8 a[12], b[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int row = 32 * kk + 8 * fq + 4 * hh + q, sw = tn_swz(row);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          const int chunk = wr * 24 + 2 * i + (pp >> 1);
+          const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(sa + row * TM + ((chunk ^ sw) << 3) + 4 * (pp & 1)));
+          a[i][4 * hh + 0] = v[0]; a[i][4 * hh + 1] = v[1]; a[i][4 * hh + 2] = v[2]; a[i][4 * hh + 3] = v[3];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int chunk = wc * 4 + 2 * j + (pp >> 1);
+          const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(sb + row * TN + ((chunk ^ sw) << 3) + 4 * (pp & 1)));
+          b[j][4 * hh + 0] = v[0]; b[j][4 * hh + 1] = v[1]; b[j][4 * hh + 2] = v[2]; b[j][4 * hh + 3] = v[3];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 12; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]),
+                                                              acc[i][j], 0, 0, 0);
+    }
+  }
+  // acc[i][j][e] = C[m0 + 192 wr + 16 i + 4 fq + e][n0 + 32 wc + 16 j + fr]
+#pragma unroll
+  for (int i = 0; i < 12; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        atomicAdd(p.C + (int64_t)(m0 + wr * 192 + i * 16 + 4 * fq + e) * p.ldc + n0 + wc * 32 + j * 16 + fr, acc[i][j][e]);
+}
+
+// ------------------------------------------------------------------------- //
 // Fused inference attention (teacher cross-encoder): one workgroup = one (batch row, head) and up to 8
 // query tiles of 32 (one per wave); K and V of the head are staged once in LDS in MFMA fragment order.
 //   S^T = K Q^T      A = K fragments [key, dim] (16 contiguous bytes of a qkv row), B = Q^T fragments
@@ -1049,23 +1167,31 @@ __global__ __launch_bounds__(256) void add_kernel(const bf16_t* __restrict__ a, 
   }
 }
 
-constexpr int COLSUM_ROWS = 64;
-typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
-// thread = one column PAIR (4-byte loads, 256 B per wave-instruction), slab of COLSUM_ROWS rows
+constexpr int COLSUM_ROWS = 256;  // rows per workgroup
+// db[c] += sum_r dY[r][c].  Thread = one 8-column chunk (16-byte loads, whole rows coalesced) of every (256 / chunks)-th
+// row of a 256-row slab; the row-threads of a chunk meet through LDS atomics, one global atomic per column and slab.
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ dY, int64_t M, int N, int64_t ld,
                                                      float* __restrict__ db) {
-  const int c = (blockIdx.x * 256 + threadIdx.x) * 2;
-  if (c >= N) return;
-  const int64_t r0 = (int64_t)blockIdx.y * COLSUM_ROWS;
-  const int64_t r1 = r0 + COLSUM_ROWS < M ? r0 + COLSUM_ROWS : M;
-  float s0 = 0.f, s1 = 0.f;
-  for (int64_t r = r0; r < r1; ++r) {
-    const bf16x2v v = *reinterpret_cast<const bf16x2v*>(dY + r * ld + c);
-    s0 += (float)v[0];
-    s1 += (float)v[1];
+  __shared__ float part[1024];  // N <= 1024 per workgroup column window
+  const int chunks = (N + 7) / 8;                 // N % 8 == 0 here
+  const int lanes_r = 256 / chunks > 0 ? 256 / chunks : 1;
+  const int c = threadIdx.x % chunks, rr = threadIdx.x / chunks;
+  for (int i = threadIdx.x; i < N; i += 256) part[i] = 0.f;
+  __syncthreads();
+  if (rr < lanes_r) {
+    const int64_t r0 = (int64_t)blockIdx.x * COLSUM_ROWS;
+    const int64_t r1 = r0 + COLSUM_ROWS < M ? r0 + COLSUM_ROWS : M;
+    float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int64_t r = r0 + rr; r < r1; r += lanes_r) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(dY + r * ld + 8 * c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s8[e] += (float)v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(&part[8 * c + e], s8[e]);
   }
-  atomicAdd(db + c, s0);
-  atomicAdd(db + c + 1, s1);
+  __syncthreads();
+  for (int i = threadIdx.x; i < N; i += 256) atomicAdd(db + i, part[i]);
 }
 
 // ------------------------------------------------------------------------- //
@@ -1301,6 +1427,40 @@ int launch_attention_bwd(const bf16_t* qkv, const int32_t* key_mask, const bf16_
   return sskd::check_launch("attention_bwd_kernel");
 }
 
+bool gemm_tn_supported(int64_t T, int M, int N, int64_t lda, int64_t ldb) {
+  return T >= 64 && T % 64 == 0 && M > 0 && M % 384 == 0 && N > 0 && N % 128 == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
+         T * lda < ((int64_t)1 << 31) && T * ldb < ((int64_t)1 << 31);
+}
+
+int launch_gemm_tn(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, float* C, int64_t ldc, int64_t T, int M,
+                   int N, hipStream_t st) {
+  SSKD_REQUIRE(A && B && C, "gemm_tn: null pointer");
+  SSKD_REQUIRE(gemm_tn_supported(T, M, N, lda, ldb), "gemm_tn: shape T=%lld M=%d N=%d not served", (long long)T, M, N);
+  SSKD_REQUIRE((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0,
+               "gemm_tn: operands must be 16-byte aligned");
+  GemmTnArgs a{};
+  a.A = A;
+  a.B = B;
+  a.C = C;
+  a.lda = lda;
+  a.ldb = ldb;
+  a.ldc = ldc;
+  a.T = T;
+  a.M = M;
+  a.N = N;
+  const int tiles = (M / 384) * (N / 128);
+  const int nk = (int)(T / 64);
+  int split = GEMM256_CUS / tiles;       // one workgroup per CU
+  if (split < 1) split = 1;
+  if (split > nk / 4) split = nk / 4 > 0 ? nk / 4 : 1;  // at least 4 K tiles per slice
+  a.k_per = (int)sskd::ceil_div(nk, split);
+  split = (int)sskd::ceil_div(nk, a.k_per);
+  constexpr int lds_bytes = 2 * (384 + 128) * 64 * 2;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn384_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  hipLaunchKernelGGL(gemm_tn384_kernel, dim3((unsigned)tiles, (unsigned)split), dim3(512), lds_bytes, st, a);
+  return sskd::check_launch("gemm_tn384_kernel");
+}
+
 int launch_transpose(const TransposeArgs& a, hipStream_t st) {
   if (a.R == 0 || a.C == 0) return SSKD_OK;
   SSKD_REQUIRE(a.R % 4 == 0 && a.C % 4 == 0 && a.ld_in % 4 == 0 && a.ld_out % 4 == 0 && a.sI1 % 4 == 0 && a.sI2 % 4 == 0 &&
@@ -1368,9 +1528,14 @@ int launch_tanh_fwd(bf16_t* x, int64_t n, hipStream_t st) {
 
 int launch_colsum(const bf16_t* dY, int64_t M, int N, int64_t ld, float* db, hipStream_t st) {
   if (M == 0 || N == 0) return SSKD_OK;
-  SSKD_REQUIRE(N % 2 == 0 && ld % 2 == 0, "colsum: N and ld must be even");
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)sskd::ceil_div(N, 512), (unsigned)sskd::ceil_div(M, COLSUM_ROWS)),
-                     dim3(256), 0, st, dY, M, N, ld, db);
+  SSKD_REQUIRE(N % 8 == 0 && ld % 8 == 0, "colsum: N and ld must be multiples of 8");
+  // column windows of at most 1024 (256 threads x ... chunks): wider matrices take several launches
+  for (int n0 = 0; n0 < N; n0 += 1024) {
+    const int w = N - n0 < 1024 ? N - n0 : 1024;
+    // 2048-wide rows would need > 256 chunks per row: windows keep chunks <= 128
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)sskd::ceil_div(M, COLSUM_ROWS)), dim3(256), 0, st, dY + n0, M, w, ld,
+                       db + n0);
+  }
   return sskd::check_launch("colsum_kernel");
 }
 

@@ -178,6 +178,25 @@ int transpose2d(const bf16_t* in, int64_t R, int C, int64_t ld_in, bf16_t* out, 
   return launch_transpose(t, st);
 }
 
+int gemm(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int N, int K,
+         const float* bias, bool c_f32, bool acc, hipStream_t st);
+
+// dW[M, N] += dY[T, M]^T X[T, N] and db[M] += column sums of dY.  The student's shapes go to the TN kernel, which
+// reads both operands as they lie in memory; others are transposed into tA / tB and take the NT kernel.
+int weight_grad(const bf16_t* dY, int M, const bf16_t* X, int N, int64_t T, float* dW, float* db, bf16_t* tA, bf16_t* tB,
+                hipStream_t st) {
+  if (gemm_tn_supported(T, M, N, M, N)) {
+    int rc = launch_colsum(dY, T, M, M, db, st);
+    if (rc != SSKD_OK) return rc;
+    return launch_gemm_tn(dY, M, X, N, dW, N, T, M, N, st);
+  }
+  int rc = transpose2d(dY, T, M, M, tA, T, st, db);  // [M, T]; db = column sums on the way
+  if (rc != SSKD_OK) return rc;
+  rc = transpose2d(X, T, N, N, tB, T, st);            // [N, T]
+  if (rc != SSKD_OK) return rc;
+  return gemm(tA, T, tB, T, dW, N, M, N, (int)T, nullptr, true, true, st);
+}
+
 #define TRY(expr)                     \
   do {                                \
     int rc_ = (expr);                 \
@@ -311,9 +330,7 @@ int layer_backward_qkv(const Dims& d, const sskd_generic_layer_weights& lw, cons
                        const bf16_t* x_in, Saved& sv, bf16_t* dqkv, const bf16_t* dz1, hipStream_t st) {
   const int H = d.H;
   const int64_t M = d.M;
-  TRY(transpose2d(dqkv, M, 3 * H, 3 * H, sv.tA, M, st, gw.bqkv));  // [3H, M]; dbqkv on the way
-  TRY(transpose2d(x_in, M, H, H, sv.tB, M, st));          // [H, M]
-  TRY(gemm(sv.tA, M, sv.tB, M, gw.wqkv, H, 3 * H, H, (int)M, nullptr, true, true, st));
+  TRY(weight_grad(dqkv, 3 * H, x_in, H, M, gw.wqkv, gw.bqkv, sv.tA, sv.tB, st));
   TRY(gemm(dqkv, 3 * H, static_cast<const bf16_t*>(lw.wqkv_t), 3 * H, sv.tH1, H, M, H, 3 * H, nullptr, false, false, st));
   TRY(launch_add(sv.tH1, dz1, sv.tH1, M * H, st));        // + residual branch of LN1
   return SSKD_OK;
@@ -328,24 +345,18 @@ int layer_backward(const Dims& d, const sskd_generic_layer_weights& lw, const ss
   bf16_t* dz2 = sv.tH0;
   TRY(launch_ln_bwd(dx2, ls.z2, ls.mean2, ls.rstd2, lw.ln2_g, M, H, dz2, gw.ln2_g, gw.ln2_b, st));
   // y = hmid W2^T + b2
-  TRY(transpose2d(dz2, M, H, H, sv.tA, M, st, gw.b2));  // [H, M]; db2 = column sums on the way
-  TRY(transpose2d(ls.hmid, M, F, F, sv.tB, M, st));    // [F, M]
-  TRY(gemm(sv.tA, M, sv.tB, M, gw.w2, F, H, F, (int)M, nullptr, true, true, st));
+  TRY(weight_grad(dz2, H, ls.hmid, F, M, gw.w2, gw.b2, sv.tA, sv.tB, st));
   TRY(gemm(dz2, H, static_cast<const bf16_t*>(lw.w2_t), H, sv.tF0, F, M, F, H, nullptr, false, false, st));  // dhmid
   TRY(launch_gelu_bwd(ls.u, sv.tF0, sv.tF0, M * F, st));  // du (in place)
   // u = x1 W1^T + b1
-  TRY(transpose2d(sv.tF0, M, F, F, sv.tA, M, st, gw.b1));  // [F, M]; db1 on the way
-  TRY(transpose2d(ls.x1, M, H, H, sv.tB, M, st));      // [H, M]
-  TRY(gemm(sv.tA, M, sv.tB, M, gw.w1, H, F, H, (int)M, nullptr, true, true, st));
+  TRY(weight_grad(sv.tF0, F, ls.x1, H, M, gw.w1, gw.b1, sv.tA, sv.tB, st));
   bf16_t* dx1 = sv.tH1;
   TRY(gemm(sv.tF0, F, static_cast<const bf16_t*>(lw.w1_t), F, dx1, H, M, H, F, nullptr, false, false, st));
   TRY(launch_add(dx1, dz2, dx1, M * H, st));           // + residual branch of LN2
   bf16_t* dz1 = sv.tH0;
   TRY(launch_ln_bwd(dx1, ls.z1, ls.mean1, ls.rstd1, lw.ln1_g, M, H, dz1, gw.ln1_g, gw.ln1_b, st));
   // attn_out = ctx Wo^T + bo
-  TRY(transpose2d(dz1, M, H, H, sv.tA, M, st, gw.bo));
-  TRY(transpose2d(ls.ctx, M, H, H, sv.tB, M, st));
-  TRY(gemm(sv.tA, M, sv.tB, M, gw.wo, H, H, H, (int)M, nullptr, true, true, st));
+  TRY(weight_grad(dz1, H, ls.ctx, H, M, gw.wo, gw.bo, sv.tA, sv.tB, st));
   bf16_t* dctx = sv.tH2;
   TRY(gemm(dz1, H, static_cast<const bf16_t*>(lw.wo_t), H, dctx, H, M, H, H, nullptr, false, false, st));
 
@@ -597,6 +608,13 @@ int sskd_gemm_nt_bf16(const void* d_a, const void* d_b, void* d_c, const float* 
                       int accumulate, void* stream) {
   return gemm(static_cast<const bf16_t*>(d_a), K, static_cast<const bf16_t*>(d_b), K, d_c, N, M, N, K, d_bias,
               c_is_f32 != 0, accumulate != 0, sskd::as_stream(stream));
+}
+
+int sskd_gemm_tn_bf16(const void* d_a, const void* d_b, float* d_c, int64_t T, int M, int N, void* stream) {
+  if (!gemm_tn_supported(T, M, N, M, N))
+    return sskd::fail(SSKD_ERR_UNSUPPORTED, "gemm_tn: T=%lld M=%d N=%d not served (M %% 384, N %% 128, T %% 64)", (long long)T, M, N);
+  return launch_gemm_tn(static_cast<const bf16_t*>(d_a), M, static_cast<const bf16_t*>(d_b), N, d_c, N, T, M, N,
+                        sskd::as_stream(stream));
 }
 
 }  // extern "C"

@@ -74,6 +74,27 @@ def test_nt_gemm_matches_torch(gpu, native_lib):
 
 
 @pytest.mark.gpu
+def test_tn_gemm_matches_torch(gpu, native_lib):
+    """C += A^T B with the token dimension as the row of both operands (transposing LDS reads, split over K)."""
+    from semantic_search_kd_amd import _native
+
+    g = torch.Generator(device="cuda").manual_seed(1)
+    st = int(torch.cuda.current_stream().cuda_stream)
+    for T, M, N in ((64, 384, 128), (4096, 384, 384), (8192, 1152, 384), (2048, 1536, 384), (1024, 384, 1536), (320, 768, 256)):
+        a = torch.randn((T, M), generator=g, device="cuda").to(torch.bfloat16)
+        b = torch.randn((T, N), generator=g, device="cuda").to(torch.bfloat16)
+        c0 = torch.randn((M, N), generator=g, device="cuda")
+        c = c0.clone()
+        _native.check(native_lib.sskd_gemm_tn_bf16(a.data_ptr(), b.data_ptr(), c.data_ptr(), T, M, N, st))
+        want = a.float().T @ b.float() + c0
+        assert (c - want).abs().max().item() <= 1e-3 * max(want.abs().max().item(), 1.0), (T, M, N)
+    # unsupported shapes are refused, not mis-computed
+    a = torch.zeros((64, 256), device="cuda", dtype=torch.bfloat16)
+    c = torch.zeros((256, 128), device="cuda")
+    assert native_lib.sskd_gemm_tn_bf16(a.data_ptr(), a.data_ptr(), c.data_ptr(), 64, 256, 128, st) != 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dims", ["small", "e5", "heads64", "long", "unfused"])
 def test_encoder_gradients_match_oracle_autograd(gpu, dims):
     from semantic_search_kd_amd.training import TrainableEncoder
