@@ -53,9 +53,10 @@ int launch_transpose(const TransposeArgs& a, hipStream_t st);
 // z = a (+ b); y = LayerNorm(z) * gamma + beta.  Optionally saves z (bf16), mean and rstd (fp32 [M]).
 int launch_add_ln_fwd(const bf16_t* a, const bf16_t* b, const float* gamma, const float* beta, float eps,
                       int64_t M, int H, bf16_t* y, bf16_t* z_save, float* mean, float* rstd, hipStream_t st);
-// dz = LN backward of dy; dgamma / dbeta (fp32 [H]) are ACCUMULATED (atomics).
+// dz = LN backward of dy; dgamma / dbeta (fp32 [H]) are ACCUMULATED (atomics); dz_colsum (optional, fp32 [H]) +=
+// column sums of dz (the bias gradient of the product whose output was normalised).
 int launch_ln_bwd(const bf16_t* dy, const bf16_t* z, const float* mean, const float* rstd, const float* gamma,
-                  int64_t M, int H, bf16_t* dz, float* dgamma, float* dbeta, hipStream_t st);
+                  int64_t M, int H, bf16_t* dz, float* dgamma, float* dbeta, hipStream_t st, float* dz_colsum = nullptr);
 
 // Inference attention, fused (no score matrix in memory): for every (batch row, head)
 //   ctx[b, :, h*DH : (h+1)*DH] = softmax(scale * Q K^T + (key masked ? -inf : 0)) V

@@ -956,16 +956,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, int64_t M, int H,
                                                      bf16_t* __restrict__ dz, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta) {
-  __shared__ float red[2][1024];
+                                                     float* __restrict__ dbeta, float* __restrict__ dz_colsum) {
+  __shared__ float red[3][1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float dg[2][8], db[2][8], gm[2][8];
+  float dg[2][8], db[2][8], gm[2][8], dzs[2][8];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int c = (lane + 64 * i) * 8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      dg[i][j] = db[i][j] = 0.f;
+      dg[i][j] = db[i][j] = dzs[i][j] = 0.f;
       gm[i][j] = c < H ? gamma[c + j] : 0.f;
     }
   }
@@ -1003,7 +1003,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       if (c < H) {
         bf16x8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(rs * (g[i][j] - s1 - xh[i][j] * s2));
+        for (int j = 0; j < 8; ++j) {
+          o[j] = (bf16_t)(rs * (g[i][j] - s1 - xh[i][j] * s2));
+          dzs[i][j] += (float)o[j];  // column sums of dz as stored: the bias gradient of the product that made z
+        }
         *reinterpret_cast<bf16x8*>(dz + row * H + c) = o;
       }
     }
@@ -1019,6 +1022,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
           for (int j = 0; j < 8; ++j) {
             red[0][c + j] = (w ? red[0][c + j] : 0.f) + dg[i][j];
             red[1][c + j] = (w ? red[1][c + j] : 0.f) + db[i][j];
+            red[2][c + j] = (w ? red[2][c + j] : 0.f) + dzs[i][j];
           }
       }
     }
@@ -1027,6 +1031,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
   for (int c = threadIdx.x; c < H; c += 256) {
     atomicAdd(dgamma + c, red[0][c]);
     atomicAdd(dbeta + c, red[1][c]);
+    if (dz_colsum) atomicAdd(dz_colsum + c, red[2][c]);
   }
 }
 
@@ -1167,7 +1172,7 @@ __global__ __launch_bounds__(256) void add_kernel(const bf16_t* __restrict__ a, 
   }
 }
 
-constexpr int COLSUM_ROWS = 256;  // rows per workgroup
+constexpr int COLSUM_ROWS = 128;  // rows per workgroup
 // db[c] += sum_r dY[r][c].  Thread = one 8-column chunk (16-byte loads, whole rows coalesced) of every (256 / chunks)-th
 // row of a 256-row slab; the row-threads of a chunk meet through LDS atomics, one global atomic per column and slab.
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ dY, int64_t M, int N, int64_t ld,
@@ -1182,7 +1187,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
     const int64_t r0 = (int64_t)blockIdx.x * COLSUM_ROWS;
     const int64_t r1 = r0 + COLSUM_ROWS < M ? r0 + COLSUM_ROWS : M;
     float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int64_t r = r0 + rr; r < r1; r += lanes_r) {
+    int64_t r = r0 + rr;
+    for (; r + 3 * lanes_r < r1; r += 4 * lanes_r) {  // four loads in flight per thread
+      bf16x8 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const bf16x8*>(dY + (r + u * lanes_r) * ld + 8 * c);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s8[e] += (float)v[u][e];
+    }
+    for (; r < r1; r += lanes_r) {
       const bf16x8 v = *reinterpret_cast<const bf16x8*>(dY + r * ld + 8 * c);
 #pragma unroll
       for (int e = 0; e < 8; ++e) s8[e] += (float)v[e];
@@ -1482,11 +1497,11 @@ int launch_add_ln_fwd(const bf16_t* a, const bf16_t* b, const float* gamma, cons
 }
 
 int launch_ln_bwd(const bf16_t* dy, const bf16_t* z, const float* mean, const float* rstd, const float* gamma,
-                  int64_t M, int H, bf16_t* dz, float* dgamma, float* dbeta, hipStream_t st) {
+                  int64_t M, int H, bf16_t* dz, float* dgamma, float* dbeta, hipStream_t st, float* dz_colsum) {
   SSKD_REQUIRE(H % 8 == 0 && H <= 1024, "layernorm: hidden=%d must be a multiple of 8, at most 1024", H);
   if (M == 0) return SSKD_OK;
   hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)sskd::ceil_div(M, LN_BWD_ROWS)), dim3(256), 0, st, dy, z, mean, rstd,
-                     gamma, M, H, dz, dgamma, dbeta);
+                     gamma, M, H, dz, dgamma, dbeta, dz_colsum);
   return sskd::check_launch("ln_bwd_kernel");
 }
 

@@ -186,8 +186,10 @@ int gemm(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, in
 int weight_grad(const bf16_t* dY, int M, const bf16_t* X, int N, int64_t T, float* dW, float* db, bf16_t* tA, bf16_t* tB,
                 hipStream_t st) {
   if (gemm_tn_supported(T, M, N, M, N)) {
-    int rc = launch_colsum(dY, T, M, M, db, st);
-    if (rc != SSKD_OK) return rc;
+    if (db) {  // nullptr: the kernel that produced dY already summed its columns
+      int rc = launch_colsum(dY, T, M, M, db, st);
+      if (rc != SSKD_OK) return rc;
+    }
     return launch_gemm_tn(dY, M, X, N, dW, N, T, M, N, st);
   }
   int rc = transpose2d(dY, T, M, M, tA, T, st, db);  // [M, T]; db = column sums on the way
@@ -343,9 +345,9 @@ int layer_backward(const Dims& d, const sskd_generic_layer_weights& lw, const ss
   const int H = d.H, S = d.S, DH = d.DH, NH = d.NH, F = d.F;
   const int64_t M = d.M;
   bf16_t* dz2 = sv.tH0;
-  TRY(launch_ln_bwd(dx2, ls.z2, ls.mean2, ls.rstd2, lw.ln2_g, M, H, dz2, gw.ln2_g, gw.ln2_b, st));
+  TRY(launch_ln_bwd(dx2, ls.z2, ls.mean2, ls.rstd2, lw.ln2_g, M, H, dz2, gw.ln2_g, gw.ln2_b, st, gw.b2));  // + db2
   // y = hmid W2^T + b2
-  TRY(weight_grad(dz2, H, ls.hmid, F, M, gw.w2, gw.b2, sv.tA, sv.tB, st));
+  TRY(weight_grad(dz2, H, ls.hmid, F, M, gw.w2, nullptr, sv.tA, sv.tB, st));
   TRY(gemm(dz2, H, static_cast<const bf16_t*>(lw.w2_t), H, sv.tF0, F, M, F, H, nullptr, false, false, st));  // dhmid
   TRY(launch_gelu_bwd(ls.u, sv.tF0, sv.tF0, M * F, st));  // du (in place)
   // u = x1 W1^T + b1
@@ -354,9 +356,9 @@ int layer_backward(const Dims& d, const sskd_generic_layer_weights& lw, const ss
   TRY(gemm(sv.tF0, F, static_cast<const bf16_t*>(lw.w1_t), F, dx1, H, M, H, F, nullptr, false, false, st));
   TRY(launch_add(dx1, dz2, dx1, M * H, st));           // + residual branch of LN2
   bf16_t* dz1 = sv.tH0;
-  TRY(launch_ln_bwd(dx1, ls.z1, ls.mean1, ls.rstd1, lw.ln1_g, M, H, dz1, gw.ln1_g, gw.ln1_b, st));
+  TRY(launch_ln_bwd(dx1, ls.z1, ls.mean1, ls.rstd1, lw.ln1_g, M, H, dz1, gw.ln1_g, gw.ln1_b, st, gw.bo));  // + dbo
   // attn_out = ctx Wo^T + bo
-  TRY(weight_grad(dz1, H, ls.ctx, H, M, gw.wo, gw.bo, sv.tA, sv.tB, st));
+  TRY(weight_grad(dz1, H, ls.ctx, H, M, gw.wo, nullptr, sv.tA, sv.tB, st));
   bf16_t* dctx = sv.tH2;
   TRY(gemm(dz1, H, static_cast<const bf16_t*>(lw.wo_t), H, dctx, H, M, H, H, nullptr, false, false, st));
 
