@@ -1233,21 +1233,33 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int32_t* __restric
   }
 }
 
+// word-embedding rows: one wave per token, fp32 atomics (ids repeat rarely inside a step)
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ mask,
-                                                        const bf16_t* __restrict__ dz, int64_t M, int S, int H, int vocab,
-                                                        int pos_offset, float* __restrict__ dword,
-                                                        float* __restrict__ dpos, float* __restrict__ dtype0) {
+                                                        const bf16_t* __restrict__ dz, int64_t M, int H, int vocab,
+                                                        float* __restrict__ dword) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M || mask[row] == 0) return;  // padding positions carry exactly zero gradient
   int id = ids[row];
   id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
-  const int t = (int)(row % S) + pos_offset;
-  for (int c = lane; c < H; c += 64) {
-    const float g = (float)dz[row * H + c];
-    atomicAdd(dword + (int64_t)id * H + c, g);
-    atomicAdd(dpos + (int64_t)t * H + c, g);
-    atomicAdd(dtype0 + c, g);
+  for (int c = lane; c < H; c += 64) atomicAdd(dword + (int64_t)id * H + c, (float)dz[row * H + c]);
+}
+
+// position / token-type rows: every sequence adds into the SAME S position rows and the one type row, so atomics
+// per token would queue B (resp. B * S) deep on each address (950 us at 65 k tokens).  One workgroup per position
+// sums its B rows in registers instead: one atomic per (position, column) and one more for the type row.
+__global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const int32_t* __restrict__ mask, const bf16_t* __restrict__ dz,
+                                                            int B, int S, int H, int pos_offset, float* __restrict__ dpos,
+                                                            float* __restrict__ dtype0) {
+  const int t = blockIdx.x;
+  for (int c = threadIdx.x; c < H; c += 256) {
+    float sum = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const int64_t row = (int64_t)b * S + t;
+      if (mask[row] != 0) sum += (float)dz[row * H + c];
+    }
+    atomicAdd(dpos + (int64_t)(t + pos_offset) * H + c, sum);
+    atomicAdd(dtype0 + c, sum);
   }
 }
 
@@ -1576,8 +1588,9 @@ int launch_embed_bwd(const int32_t* ids, const int32_t* mask, const bf16_t* dz, 
                      int pos_offset, float* dword, float* dpos, float* dtype0, hipStream_t st) {
   const int64_t M = (int64_t)B * S;
   if (M == 0) return SSKD_OK;
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)sskd::ceil_div(M, 4)), dim3(256), 0, st, ids, mask, dz, M, S, H,
-                     vocab, pos_offset, dword, dpos, dtype0);
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)sskd::ceil_div(M, 4)), dim3(256), 0, st, ids, mask, dz, M, H, vocab,
+                     dword);
+  hipLaunchKernelGGL(embed_pos_bwd_kernel, dim3((unsigned)S), dim3(256), 0, st, mask, dz, B, S, H, pos_offset, dpos, dtype0);
   return sskd::check_launch("embed_bwd_kernel");
 }
 
