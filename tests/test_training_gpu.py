@@ -144,6 +144,25 @@ def test_encoder_gradients_match_oracle_autograd(gpu, dims):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["stress_l2", "stress_l12"])
+def test_trainable_forward_on_stress_weights_matches_transformers_golden(gpu, tag):
+    """The generic row-major path (256-tile GEMMs, fused attention with saved log-sum-exp) on the hard-case
+    weights - peaky softmax rows, LayerNorm gains in [0.3, 3], +-10 outlier channels - against the committed
+    transformers.BertModel embeddings: the same gate as the specialised inference kernels
+    (tests/test_encoder_gpu.py), so the training forward is not only exercised on benign weights."""
+    from conftest import GOLDEN
+    from semantic_search_kd_amd.training import TrainableEncoder
+
+    gold = np.load(GOLDEN / f"bert_{tag}.npz")
+    cfg = BertConfig(num_hidden_layers=int(gold["layers"]))
+    model = TrainableEncoder(cfg, synthetic_state_dict(cfg, stress=True), "cuda:0")
+    with torch.no_grad():
+        emb = model(gold["input_ids"], gold["attention_mask"], normalize=True).cpu().numpy()
+    cos = [_cos(emb[i], gold["embeddings"][i]) for i in range(emb.shape[0])]
+    assert min(cos) >= 0.999, cos
+
+
+@pytest.mark.gpu
 def test_kd_training_step_matches_oracle_and_learns(gpu):
     """The reference's step (src/kd/train.py:176-210) on the HIP path: encode_with_gradients twice ->
     q @ d.T -> CombinedKDLoss (HIP) -> backward -> AdamW; loss and gradients vs the oracle chain
