@@ -262,3 +262,28 @@ def test_ance_miner_matches_reference_fixture():
             got = ANCEMiner(HashedEmbeddingStudent(), margin=margin).mine(queries, positives, candidates, docs, docs, top_k=top_k)
             assert got == gold[f"margin{margin}_k{top_k}"], (margin, top_k)
     assert ANCEMiner(HashedEmbeddingStudent()).mine([], [], [], {}, {}) == []
+
+
+def test_screened_search_launch_plan_is_sane_across_shapes():
+    """The screening launch plan is a host function of the shape (no GPU needed): every served shape gets a
+    positive workspace, 64 or 128 queries per workgroup, at least one slice, and never more workgroups in
+    flight per round than the planner's cost model assumes; unserved shapes are refused, not mis-planned."""
+    import ctypes
+
+    from semantic_search_kd_amd import _native
+
+    lib = _native.load()
+    for n, nq in [(2048, 64), (2049, 65), (4000, 10000), (125_000, 10_000), (1_000_000, 10_000), (8_841_823, 10_000),
+                  (1_000_000, 1250), (1_000_000, 256), (1_000_000, 255), (33_000, 100_000), (70_001, 2999)]:
+        qpb, passes, slices = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        rc = lib.sskd_index_search_screened_plan(n, nq, 10, ctypes.byref(qpb), ctypes.byref(passes), ctypes.byref(slices))
+        assert rc == 0, (n, nq)
+        assert qpb.value == (128 if nq >= 256 else 64)
+        assert passes.value == -(-nq // qpb.value)
+        tiles = -(-n // 32)
+        assert 1 <= slices.value <= max(1, -(-tiles // 8)), (n, nq, slices.value)
+        assert int(lib.sskd_index_search_screened_workspace_bytes(n, nq, 10)) > 0
+        assert int(lib.sskd_index_bf16_bytes(n)) >= tiles * 32 * (768 + 1536)   # bf16 tiles + row-major fp32 rows
+    for n, nq, k in [(2047, 64, 10), (100_000, 63, 10), (100_000, 1000, 11), (100_000, 1000, 0)]:
+        assert int(lib.sskd_index_search_screened_workspace_bytes(n, nq, k)) == 0
+        assert lib.sskd_index_search_screened_plan(n, nq, k, None, None, None) != 0
