@@ -127,16 +127,20 @@ int sskd_index_search_profiled(const float* d_tiled, int64_t n_rows,
 
 /* Screened search for batch shapes (k <= 10, nq >= 64, >= 2048 rows): a bf16-MFMA screening pass
  * (16x the fp32 matrix rate) over a bf16 copy of the index, then exact fp32 re-scoring of the
- * candidates inside a PROVED error band (|screen - exact| <= 0.0041 |q| max|row|, Cauchy-Schwarz on
- * the bf16 rounding), so scores and ids are bit-identical to sskd_index_search's.  Queries whose
- * candidate band cannot be proven complete (a per-lane list full inside the band: duplicate-heavy
- * neighbourhoods) are answered by the exact scan inside the same call, up to 1024 of them.
- * d_status (device int[2]): [0] = 0 ok, 1 = more than 1024 unproven queries - their output rows
- * hold (NaN, -2) and the caller must re-run sskd_index_search; [1] = queries that took the exact
- * fallback.  d_bf16: the screening sidecar, sskd_index_bf16_bytes(n_rows) bytes filled by
- * sskd_index_make_bf16 from the CURRENT tiled index (re-make it after sskd_index_add_rows): the bf16
- * tiles (768 B per row), max |row|^2, and the fp32 rows row-major (1536 B per row: the re-scoring
- * gathers read whole cache lines from it). */
+ * candidates inside a PROVED error band, so scores and ids are bit-identical to sskd_index_search's.
+ * The band is measured, not assumed: |screen - exact| <= |q~ - q| max|row~| + |q| max|row~ - row| +
+ * 1e-4 |q| max|row| (Cauchy-Schwarz on the two bf16 roundings + fp32 accumulation slack), with the
+ * query norms taken per query and the row maxima when the sidecar is made; in the worst case (every
+ * element on a bf16 tie) that is 2^-7 (1 + 2^-9) |q| max|row|, on random data about 0.42 of it.
+ * Queries whose candidate band cannot be proven complete (a per-lane list full inside the band:
+ * duplicate-heavy neighbourhoods) are answered by the exact scan inside the same call - the in-call
+ * fallback is sized for every query, so no output row is ever unproven and callers have nothing to
+ * check.  d_status (device int[2]): [0] = always 0 (kept for ABI stability), [1] = the number of
+ * queries that took the exact fallback (a cost diagnostic).  d_bf16: the screening sidecar,
+ * sskd_index_bf16_bytes(n_rows) bytes filled by sskd_index_make_bf16 from the CURRENT tiled index
+ * (re-make it after sskd_index_add_rows): the bf16 tiles (768 B per row), a 256-byte block with
+ * max |row|^2, max |row~|^2 and max |row~ - row|^2, and the fp32 rows row-major (1536 B per row: the
+ * re-scoring gathers read whole cache lines from it). */
 size_t sskd_index_bf16_bytes(int64_t n_rows);
 int sskd_index_make_bf16(const float* d_tiled, int64_t n_rows, void* d_bf16, void* stream);
 size_t sskd_index_search_screened_workspace_bytes(int64_t n_rows, int nq, int k);
@@ -393,10 +397,11 @@ int sskd_generic_backward(const sskd_generic_config* cfg, const sskd_generic_wei
  * src/mining/miners.py:135-137, src/serve/app.py:325-326; model = XLM-R-large shaped
  * XLMRobertaForSequenceClassification with one label, docs/adr-002): generic encoder forward ->
  * hidden state of token 0 -> dense [H, H] + tanh -> out_proj [1, H] -> d_logits fp32 [B] (raw logits).
- * head weights bf16 row-major [out, in], biases fp32. */
+ * The head runs in fp32: head weights fp32 row-major [out, in], biases fp32 (a reranker's product is the
+ * ORDER of its logits; the head is 0.002 % of the FLOPs). */
 size_t sskd_teacher_workspace_bytes(const sskd_generic_config* cfg, int B, int S);
-int sskd_teacher_score(const sskd_generic_config* cfg, const sskd_generic_weights* w, const void* d_head_dense_w,
-                       const float* d_head_dense_b, const void* d_head_out_w, const float* d_head_out_b,
+int sskd_teacher_score(const sskd_generic_config* cfg, const sskd_generic_weights* w, const float* d_head_dense_w,
+                       const float* d_head_dense_b, const float* d_head_out_w, const float* d_head_out_b,
                        const int32_t* d_ids, const int32_t* d_mask, int B, int S, float* d_logits, void* d_workspace,
                        size_t workspace_bytes, void* stream);
 

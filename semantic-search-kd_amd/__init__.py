@@ -13,7 +13,7 @@ from .weights import BertConfig, synthetic_state_dict  # noqa: F401
 from .encoder import Mi355xSentenceEncoder, build_wordpiece_tokenizer  # noqa: F401
 from .student import StudentModel  # noqa: F401
 from .losses import CombinedKDLoss, ContrastiveLoss, ListwiseKDLoss, MarginMSELoss  # noqa: F401
-from .mining import ANCEMiner  # noqa: F401
+from .mining import ANCEMiner, TeacherMiner  # noqa: F401
 from .teacher import TeacherConfig, TeacherModel  # noqa: F401
 from .bench_support import bench_encode, encoder_smoke_embeddings  # noqa: F401
 
@@ -21,6 +21,7 @@ Mi355xIndexBuilder = FAISSIndexBuilder
 
 __all__ = [
     "ANCEMiner",
+    "TeacherMiner",
     "TeacherConfig",
     "TeacherModel",
     "CombinedKDLoss",

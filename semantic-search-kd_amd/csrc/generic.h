@@ -81,7 +81,6 @@ int launch_softmax_bwd(bf16_t* dP, const bf16_t* P, int64_t rows, int S, float s
 
 int launch_gelu_fwd(const bf16_t* u, bf16_t* h, int64_t n, hipStream_t st);
 int launch_gelu_bwd(const bf16_t* u, const bf16_t* dh, bf16_t* du, int64_t n, hipStream_t st);
-int launch_tanh_fwd(bf16_t* x, int64_t n, hipStream_t st);  // in place
 
 // db[N] += sum_m dY[m, N]  (fp32, accumulated with atomics)
 int launch_colsum(const bf16_t* dY, int64_t M, int N, int64_t ld, float* db, hipStream_t st);

@@ -1156,11 +1156,6 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict_
   }
 }
 
-__global__ __launch_bounds__(256) void tanh_kernel(bf16_t* __restrict__ x, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-    x[i] = (bf16_t)tanhf((float)x[i]);
-}
-
 __global__ __launch_bounds__(256) void add_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
                                                   bf16_t* __restrict__ c, int64_t n8) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
@@ -1545,12 +1540,6 @@ int launch_gelu_bwd(const bf16_t* u, const bf16_t* dh, bf16_t* du, int64_t n, hi
   if (n == 0) return SSKD_OK;
   hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid1d(n / 8)), dim3(256), 0, st, u, dh, du, n / 8);
   return sskd::check_launch("gelu_bwd_kernel");
-}
-
-int launch_tanh_fwd(bf16_t* x, int64_t n, hipStream_t st) {
-  if (n == 0) return SSKD_OK;
-  hipLaunchKernelGGL(tanh_kernel, dim3(grid1d(n)), dim3(256), 0, st, x, n);
-  return sskd::check_launch("tanh_kernel");
 }
 
 int launch_colsum(const bf16_t* dY, int64_t M, int N, int64_t ld, float* db, hipStream_t st) {

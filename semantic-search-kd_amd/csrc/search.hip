@@ -723,14 +723,22 @@ __global__ __launch_bounds__(64) void similarity_kernel(const float* __restrict_
 //
 // The exact scan above is bound by the fp32 matrix pipe (~0.9 of its peak).  bf16 MFMAs run 16x
 // faster, so a SCREENING pass computes every score from bf16-rounded rows and queries first.
-// With e = (2^-8 (1 + 2^-9) + fp32 accumulation slack) |q| max|c| as a PROVED bound on
-// |screen score - exact fp32 score| (Cauchy-Schwarz on the two rounding errors), every row of the
+// Error bound, PROVED and data-dependent: with q~, c~ the rounded vectors,
+//   q~.c~ - q.c = (q~ - q).c~ + q.(c~ - c),  so  |q~.c~ - q.c| <= |q~ - q| |c~| + |q| |c~ - c|  (Cauchy-Schwarz).
+// |q~ - q| and |q| are MEASURED per query (screen_eps_kernel; q - q~ is exact in fp32), max |c~|, max |c~ - c|
+// and max |c| over the rows are MEASURED when the bf16 copy is made (make_bf16_tiles_kernel).  On top,
+// SCREEN_ACC_SLACK |q| max|c| covers the fp32 accumulation roundings of both dot products.  Worst case
+// (every element on a bf16 tie: relative rounding error 2^-8 per element, bf16 has 8 significand bits) this
+// is e = 2^-7 (1 + 2^-9) |q| |c|; random data rounds to about 0.42 of that.  Nothing about the rounding
+// mode is assumed - whatever the conversion did is what gets measured.
+// With e bounding |screen score - exact fp32 score|, every row of the
 // exact top k has a screen score >= (k-th best screen score) - 2e: those rows are the candidates.
 // They are re-scored with the exact k-ordered fma chain of the fp32 MFMA, so the final scores and
 // ids are bit-identical to the exact scan's.  The per-lane lists can truncate the candidate set
 // only where a list is FULL with its last entry still inside the candidate band; that is detected
 // per query, and such queries (duplicate-heavy neighbourhoods) are answered by the exact scan in
-// a fallback launch sized for SCREEN_FALLBACK_CAP queries - results are never approximate.
+// a fallback launch sized for EVERY query of the call - results are never approximate and no
+// entry point can return an unproven row.
 // ------------------------------------------------------------------------- //
 typedef __bf16 sbf16x8 __attribute__((ext_vector_type(8)));
 constexpr int BSTEPS = DIM / 16;                 // 24 k-steps of the 32x32x16 bf16 MFMA
@@ -753,8 +761,10 @@ constexpr int SCREEN_WAVES = SSKD_SCREEN_WAVES;  // waves per screening workgrou
 constexpr int SCREEN_RING = SSKD_SCREEN_RING;    // register buffers of one group each; RING - 1 groups are in flight
 constexpr int SCREEN_LISTK = SSKD_SCREEN_LISTK;  // depth of the per-lane lists (the pools keep 10 slots regardless)
 static_assert(BSTEPS % BGROUP == 0 && BGROUPS % SCREEN_RING == 0 && SCREEN_RING >= 2, "screening prefetch geometry");
-constexpr float SCREEN_EPS_REL = 0.0041f;        // >= 2^-8 (1 + 2^-9) + 3 x 384 x 2^-24, see above
-constexpr int SCREEN_FALLBACK_CAP = 1024;        // queries the exact fallback launch is sized for
+// fp32 accumulation slack of the two dot products, relative to |q| max|c|: the exact score is a 384-step fma
+// chain (<= 384 x 2^-24), the screen score 24 MFMAs of 16 exact products each accumulated in fp32 (<= 2 x 384
+// x 2^-24 even if every internal add truncated); 3 x 384 x 2^-24 (1 + 2^-8)^2 = 6.9e-5, rounded up generously
+constexpr float SCREEN_ACC_SLACK = 1.0e-4f;
 constexpr int SCREEN_MAX_CAND = 256;             // candidates re-scored per query (one per thread)
 constexpr int SCREEN_MAX_ENTRIES = 4096;         // list entries of one query staged in LDS
 constexpr int SCREEN_CUS = 256;                  // MI355X: the launch geometry is planned in whole rounds of the chip
@@ -767,39 +777,63 @@ constexpr int SCREEN_CUS = 256;                  // MI355X: the launch geometry 
 __global__ __launch_bounds__(256) void make_bf16_tiles_kernel(const float4* __restrict__ tiled, int64_t n_tiles,
                                                               sbf16x8* __restrict__ out, int* __restrict__ max_norm2,
                                                               float4* __restrict__ rows_rm) {
-  __shared__ float rowss[32];
+  __shared__ float rowss[3][32];   // per row: |c|^2, |c~|^2, |c~ - c|^2
   const int64_t t = blockIdx.x;
-  if (threadIdx.x < 32) rowss[threadIdx.x] = 0.f;
+  if (threadIdx.x < 96) rowss[threadIdx.x >> 5][threadIdx.x & 31] = 0.f;
   __syncthreads();
   const float4* src = tiled + t * (int64_t)(TILE_ROWS * CHUNKS);
   for (int v = threadIdx.x; v < BTILE_VEC; v += 256) {
     const int sidx = v >> 6, l = v & 63, r = l & 31, hh = l >> 5;
     const int u = 2 * sidx + hh;
     const float4 a = src[u * 64 + r], b = src[u * 64 + r + 32];
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     sbf16x8 o;
-    o[0] = (__bf16)a.x; o[1] = (__bf16)a.y; o[2] = (__bf16)a.z; o[3] = (__bf16)a.w;
-    o[4] = (__bf16)b.x; o[5] = (__bf16)b.y; o[6] = (__bf16)b.z; o[7] = (__bf16)b.w;
+    float nn = 0.f, bb = 0.f, dd = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      o[e] = (__bf16)x[e];
+      const float xr = (float)o[e];
+      const float d = xr - x[e];     // exact in fp32: xr is x[e] rounded to fewer bits
+      nn = fmaf(x[e], x[e], nn);
+      bb = fmaf(xr, xr, bb);
+      dd = fmaf(d, d, dd);
+    }
     out[t * BTILE_VEC + v] = o;
     float4* const dst = rows_rm + (t * TILE_ROWS + r) * (int64_t)(DIM / 4) + 2 * u;  // columns 8u .. 8u + 7
     dst[0] = a;
     dst[1] = b;
-    atomicAdd(&rowss[r], a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w);
+    atomicAdd(&rowss[0][r], nn);
+    atomicAdd(&rowss[1][r], bb);
+    atomicAdd(&rowss[2][r], dd);
   }
   __syncthreads();
-  if (threadIdx.x < 32) atomicMax(max_norm2, __float_as_int(rowss[threadIdx.x]));  // non-negative floats order as ints
+  // non-negative floats order as ints; words 0..2 of the sidecar's norm block
+  if (threadIdx.x < 96) atomicMax(max_norm2 + (threadIdx.x >> 5), __float_as_int(rowss[threadIdx.x >> 5][threadIdx.x & 31]));
 }
 
-// per query: 2e = 2 SCREEN_EPS_REL |q| max|c|
+// per query: 2e = 2 (|q~ - q| max|c~| + |q| max|c~ - c| + SCREEN_ACC_SLACK |q| max|c|), rounded UP
 __global__ __launch_bounds__(256) void screen_eps_kernel(const float* __restrict__ queries, int nq,
                                                          const int* __restrict__ max_norm2, float* __restrict__ eps2) {
   const int lane = threadIdx.x & 63;
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= nq) return;
-  float ss = 0.f;
-  for (int i = lane; i < DIM; i += 64) ss += queries[(int64_t)q * DIM + i] * queries[(int64_t)q * DIM + i];
+  float ss = 0.f, dd = 0.f;
+  for (int i = lane; i < DIM; i += 64) {
+    const float x = queries[(int64_t)q * DIM + i];
+    const float d = (float)(__bf16)x - x;   // the same conversion the screening kernel applies; exact difference
+    ss = fmaf(x, x, ss);
+    dd = fmaf(d, d, dd);
+  }
   ss = wave_sum(ss);
-  // round the bound UP a little: sqrt / multiply roundings must not shrink it
-  if (lane == 0) eps2[q] = 2.0f * SCREEN_EPS_REL * sqrtf(ss) * sqrtf(__int_as_float(*max_norm2)) * 1.0001f + 1e-30f;
+  dd = wave_sum(dd);
+  if (lane == 0) {
+    const float cn = sqrtf(__int_as_float(max_norm2[0])), cb = sqrtf(__int_as_float(max_norm2[1])),
+                cd = sqrtf(__int_as_float(max_norm2[2]));
+    const float qn = sqrtf(ss), qd = sqrtf(dd);
+    // the sums of squares carry <= 385 x 2^-24 relative error, the square roots and products a few ulps more:
+    // 1.0002 rounds the whole bound up
+    eps2[q] = 2.0f * (qd * cb + qn * cd + SCREEN_ACC_SLACK * qn * cn) * 1.0002f + 1e-30f;
+  }
 }
 
 struct ScreenParams {
@@ -1021,9 +1055,8 @@ struct ScreenFinalParams {
   float* out_scores;          // [nq][k]
   int64_t* out_ids;
   int* fb_count;              // [1] pre-zeroed: queries handed to the exact fallback
-  int* fb_qid;                // [SCREEN_FALLBACK_CAP]
-  float* fb_queries;          // [SCREEN_FALLBACK_CAP][384]
-  int* status;                // [1] pre-zeroed: 1 = more unproven queries than the fallback holds
+  int* fb_qid;                // [nq]: the fallback holds every query of the call, it cannot overflow
+  float* fb_queries;          // [nq][384]
 };
 
 // wave-wide arg-best in rank order (higher score, then lower id); i < 0 = nothing
@@ -1103,19 +1136,11 @@ __global__ __launch_bounds__(64) void screen_finalize_kernel(ScreenFinalParams p
   if (__any(bad)) {
     int slot = 0;
     if (lane == 0) {
-      slot = atomicAdd(p.fb_count, 1);
-      if (slot < SCREEN_FALLBACK_CAP) p.fb_qid[slot] = q;
-      else atomicMax(p.status, 1);
+      slot = atomicAdd(p.fb_count, 1);   // < nq: one add per query at most
+      p.fb_qid[slot] = q;
     }
     slot = __shfl(slot, 0);
-    if (slot < SCREEN_FALLBACK_CAP) {
-      for (int c = lane; c < DIM; c += 64) p.fb_queries[(int64_t)slot * DIM + c] = qv[c];
-    } else {
-      for (int r = lane; r < p.k; r += 64) {  // loud, never plausible
-        p.out_scores[(int64_t)q * p.k + r] = __int_as_float(0x7fc00000);
-        p.out_ids[(int64_t)q * p.k + r] = -2;
-      }
-    }
+    for (int c = lane; c < DIM; c += 64) p.fb_queries[(int64_t)slot * DIM + c] = qv[c];
     return;
   }
   __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -1176,7 +1201,7 @@ __global__ __launch_bounds__(256) void screen_scatter_kernel(const int* __restri
                                                              const float* __restrict__ fb_scores,
                                                              const int64_t* __restrict__ fb_ids, int k,
                                                              float* __restrict__ out_scores, int64_t* __restrict__ out_ids) {
-  const int n = min(*fb_count, SCREEN_FALLBACK_CAP);
+  const int n = *fb_count;
   for (int i = blockIdx.x; i < n; i += gridDim.x) {
     const int q = fb_qid[i];
     for (int r = threadIdx.x; r < k; r += 256) {
@@ -1813,11 +1838,13 @@ ScreenWs screen_carve(void* base, const ScreenPlan& pl, int64_t n_rows, int nq, 
   w.tau = static_cast<int*>(take((size_t)nq * 11 * sizeof(int)));
   w.eps2 = static_cast<float*>(take((size_t)nq * sizeof(float)));
   w.fb_count = static_cast<int*>(take(256));
-  w.fb_qid = static_cast<int*>(take(SCREEN_FALLBACK_CAP * sizeof(int)));
-  w.fb_queries = static_cast<float*>(take((size_t)SCREEN_FALLBACK_CAP * DIM * sizeof(float)));
-  w.fb_scores = static_cast<float*>(take((size_t)SCREEN_FALLBACK_CAP * k * sizeof(float)));
-  w.fb_ids = static_cast<int64_t*>(take((size_t)SCREEN_FALLBACK_CAP * k * sizeof(int64_t)));
-  w.exact_bytes = sskd_index_search_workspace_bytes(n_rows, SCREEN_FALLBACK_CAP, k);
+  // the in-call exact fallback is sized for EVERY query: however many candidate bands cannot be proven
+  // complete, the call answers them itself (its launches read the actual count from device memory)
+  w.fb_qid = static_cast<int*>(take((size_t)nq * sizeof(int)));
+  w.fb_queries = static_cast<float*>(take((size_t)nq * DIM * sizeof(float)));
+  w.fb_scores = static_cast<float*>(take((size_t)nq * k * sizeof(float)));
+  w.fb_ids = static_cast<int64_t*>(take((size_t)nq * k * sizeof(int64_t)));
+  w.exact_bytes = sskd_index_search_workspace_bytes(n_rows, nq, k);
   w.exact_ws = take(w.exact_bytes);
   w.bytes = (size_t)(p - static_cast<char*>(base));
   return w;
@@ -1942,14 +1969,13 @@ int sskd_index_search_screened(const float* d_tiled, const void* d_bf16, int64_t
   fp.fb_count = w.fb_count;
   fp.fb_qid = w.fb_qid;
   fp.fb_queries = w.fb_queries;
-  fp.status = d_status;
   const size_t fin_lds = ((size_t)2 * pl.lists_per_query * pl.LK + DIM + SCREEN_MAX_CAND) * sizeof(float);
   hipLaunchKernelGGL(screen_finalize_kernel, dim3(nq), dim3(64), fin_lds, st, fp);
   if ((rc = sskd::check_launch("screen_finalize_kernel")) != SSKD_OK) return rc;
 
   // exact scan for the queries whose candidate band could not be proven complete (usually none:
   // every workgroup of these launches then exits on its first instruction)
-  rc = exact_search_impl(d_tiled, n_rows, w.fb_queries, SCREEN_FALLBACK_CAP, k, id_offset, w.fb_scores, w.fb_ids,
+  rc = exact_search_impl(d_tiled, n_rows, w.fb_queries, nq, k, id_offset, w.fb_scores, w.fb_ids,
                          w.exact_ws, w.exact_bytes, stream, nullptr, nullptr, nullptr, w.fb_count);
   if (rc != SSKD_OK) return rc;
   hipLaunchKernelGGL(screen_scatter_kernel, dim3(64), dim3(256), 0, st, w.fb_count, w.fb_qid, w.fb_scores, w.fb_ids, k,

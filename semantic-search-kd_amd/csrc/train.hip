@@ -484,11 +484,34 @@ int layer_backward(const Dims& d, const sskd_generic_layer_weights& lw, const ss
   return layer_backward_qkv(d, lw, gw, x_in, sv, dqkv, dz1, st);
 }
 
-// Cross-encoder head input: hidden state of token 0 (<s>) of every sequence
-__global__ __launch_bounds__(256) void gather_first_token_kernel(const bf16_t* __restrict__ hidden, int S, int H,
-                                                                 bf16_t* __restrict__ out) {
-  const int b = blockIdx.x;
-  for (int c = threadIdx.x; c < H; c += 256) out[(int64_t)b * H + c] = hidden[(int64_t)b * S * H + c];
+// Cross-encoder head, one workgroup per sequence, ALL in fp32 (RobertaClassificationHead with one label):
+//   logit = out_w . tanh(dense_w . h[<s>] + dense_b) + out_b
+// A reranker's product is an ordering of near-equal logits, and the head is 2 H^2 FLOPs per pair (0.002 % of the
+// encoder's work): there is nothing to gain from bf16 here, and the round-2 bf16 head (bf16 dense output, bf16
+// tanh, bf16 weights) added its own rounding on top of the encoder's.  Wave w computes dense rows w, w + 4, ...
+// (one coalesced fp32 row read per wave-instruction, the <s> state in LDS), then a fixed-order block reduction.
+__global__ __launch_bounds__(256) void teacher_head_kernel(const bf16_t* __restrict__ hidden, int S, int H,
+                                                           const float* __restrict__ dense_w, const float* __restrict__ dense_b,
+                                                           const float* __restrict__ out_w, const float* __restrict__ out_b,
+                                                           float* __restrict__ logits) {
+  __shared__ float xs[1024];
+  __shared__ float part[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bf16_t* h = hidden + (int64_t)b * S * H;   // token 0 of sequence b
+  for (int c = tid; c < H; c += 256) xs[c] = (float)h[c];
+  __syncthreads();
+  float acc = 0.f;   // this wave's share of sum_r out_w[r] tanh(...)
+  for (int r = wave; r < H; r += 4) {
+    const float* wr = dense_w + (int64_t)r * H;
+    float d = 0.f;
+    for (int c = lane; c < H; c += 64) d = fmaf(wr[c], xs[c], d);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+    acc = fmaf(out_w[r], tanhf(d + dense_b[r]), acc);   // identical in every lane of the wave
+  }
+  if (lane == 0) part[wave] = acc;
+  __syncthreads();
+  if (tid == 0) logits[b] = ((part[0] + part[1]) + (part[2] + part[3])) + out_b[0];
 }
 
 }  // namespace
@@ -569,40 +592,31 @@ int sskd_generic_backward(const sskd_generic_config* cfg, const sskd_generic_wei
 }
 
 size_t sskd_teacher_workspace_bytes(const sskd_generic_config* cfg, int B, int S) {
-  const size_t enc = sskd_generic_workspace_bytes(cfg, B, S, 0);
-  if (enc == 0) return 0;
-  const size_t BH = ((size_t)(B > 32 ? B : 32) * cfg->hidden * sizeof(bf16_t) + 255) & ~(size_t)255;
-  return enc + 2 * BH;
+  return sskd_generic_workspace_bytes(cfg, B, S, 0);
 }
 
 // Cross-encoder score: generic encoder -> hidden state of token 0 (<s>) -> dense + tanh -> out_proj
-// (XLMRobertaForSequenceClassification's RobertaClassificationHead with num_labels = 1).
-int sskd_teacher_score(const sskd_generic_config* cfg, const sskd_generic_weights* w, const void* d_head_dense_w,
-                       const float* d_head_dense_b, const void* d_head_out_w, const float* d_head_out_b,
+// (XLMRobertaForSequenceClassification's RobertaClassificationHead with num_labels = 1); the head runs in fp32.
+int sskd_teacher_score(const sskd_generic_config* cfg, const sskd_generic_weights* w, const float* d_head_dense_w,
+                       const float* d_head_dense_b, const float* d_head_out_w, const float* d_head_out_b,
                        const int32_t* d_ids, const int32_t* d_mask, int B, int S, float* d_logits, void* d_workspace,
                        size_t workspace_bytes, void* stream) {
   Dims d{};
   std::vector<LayerSaved> layers;
   Saved sv{};
-  const size_t enc_bytes = cfg ? sskd_generic_workspace_bytes(cfg, B, S, 0) : 0;
   const size_t need = cfg ? sskd_teacher_workspace_bytes(cfg, B, S) : 0;
   if (B > 0 && (!d_workspace || workspace_bytes < need))
     return sskd::fail(SSKD_ERR_WORKSPACE, "teacher_score: workspace %zu B < required %zu B", workspace_bytes, need);
-  int rc = prepare(cfg, w, B, S, 0, d_workspace, enc_bytes, &d, &layers, &sv);
+  int rc = prepare(cfg, w, B, S, 0, d_workspace, need, &d, &layers, &sv);
   if (rc != SSKD_OK || B == 0) return rc;
   SSKD_REQUIRE(d_head_dense_w && d_head_dense_b && d_head_out_w && d_head_out_b && d_ids && d_mask && d_logits,
                "teacher_score: null pointer");
   hipStream_t st = sskd::as_stream(stream);
   const bf16_t* fin = nullptr;
   TRY(forward_all(cfg, w, d, d_ids, d_mask, sv, st, &fin));
-  const size_t BH = ((size_t)(B > 32 ? B : 32) * d.H * sizeof(bf16_t) + 255) & ~(size_t)255;
-  bf16_t* cls = reinterpret_cast<bf16_t*>(static_cast<char*>(d_workspace) + enc_bytes);
-  bf16_t* hid = reinterpret_cast<bf16_t*>(static_cast<char*>(d_workspace) + enc_bytes + BH);
-  hipLaunchKernelGGL(gather_first_token_kernel, dim3(B), dim3(256), 0, st, fin, S, d.H, cls);
-  TRY(sskd::check_launch("gather_first_token_kernel"));
-  TRY(gemm(cls, d.H, static_cast<const bf16_t*>(d_head_dense_w), d.H, hid, d.H, B, d.H, d.H, d_head_dense_b, false, false, st));
-  TRY(launch_tanh_fwd(hid, (int64_t)B * d.H, st));
-  return gemm(hid, d.H, static_cast<const bf16_t*>(d_head_out_w), d.H, d_logits, 1, B, 1, d.H, d_head_out_b, true, false, st);
+  hipLaunchKernelGGL(teacher_head_kernel, dim3(B), dim3(256), 0, st, fin, S, d.H, d_head_dense_w, d_head_dense_b,
+                     d_head_out_w, d_head_out_b, d_logits);
+  return sskd::check_launch("teacher_head_kernel");
 }
 
 // test hook: the NT GEMM by itself

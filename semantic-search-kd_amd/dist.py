@@ -78,6 +78,32 @@ def hip_merge_packed(records: torch.Tensor, g: int, nq: int, k_in: int, k_out: i
     return out_s, out_i
 
 
+def sharded_scores(score_fn: Callable[[int, int], torch.Tensor], n_items: int, group=None,
+                   device: Optional[torch.device] = None) -> torch.Tensor:
+    """Pure data parallelism over ``n_items`` independent work items (teacher scoring, BASELINE cfg 5;
+    SURVEY.md section 8e: "pure DP over pairs with a final concat").
+
+    Rank r computes ``score_fn(lo, hi) -> fp32 [hi - lo]`` for its contiguous range ``shard_bounds(n_items, G, r)``;
+    ONE ``all_gather_into_tensor`` of ceil(n / G) floats per rank is the final concat - every rank returns all
+    ``n_items`` scores in item order.  No collective inside the scoring itself.  Without an initialised process
+    group (or world size 1) this is just ``score_fn(0, n_items)``."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return score_fn(0, n_items)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi = shard_bounds(n_items, world, rank)
+    local = score_fn(lo, hi) if hi > lo else torch.empty(0, dtype=torch.float32, device=device)
+    # gloo moves host tensors, nccl (= RCCL) device tensors
+    comm_dev = torch.device("cpu") if dist.get_backend(group) == "gloo" else local.device
+    per = -(-n_items // world)
+    send = torch.zeros(per, dtype=torch.float32, device=comm_dev)
+    send[: hi - lo] = local.to(comm_dev, torch.float32)
+    recv = torch.empty(world * per, dtype=torch.float32, device=comm_dev)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    return recv[:n_items].to(local.device)   # ceil-sized shards: only the tail of the LAST ranks is padding
+
+
 class ShardedSearcher:
     """Search a corpus whose rows are split over the ranks of a process group."""
 

@@ -87,12 +87,15 @@ class FAISSIndexBuilder:
         # search call; ``None`` = the built-in plan.  There is no environment knob behind the search.
         self.search_tuning: Optional[_native.SearchTuning] = None
         # batch searches (k <= 10, >= 64 queries) go through the bf16-screened path: identical bits to
-        # the exact scan (proved error band + exact re-scoring + exact fallback), several times faster.
+        # the exact scan (measured + proved error band, exact re-scoring, in-call exact fallback sized for
+        # every query - no caller ever has to check a status), several times faster.
         # ``screening = False`` forces the plain exact scan.
         self.screening = True
         self._bf16: Optional[torch.Tensor] = None      # screening sidecar (bf16 tiles, max row norm, row-major fp32 rows), made lazily
         self._bf16_rows = -1
-        self.last_status: Optional[torch.Tensor] = None  # device int32[2] of the last screened search
+        # device int32[2] of the last screened search: [0] always 0, [1] = queries that took the in-call
+        # exact fallback (a cost diagnostic; nothing to act on)
+        self.last_status: Optional[torch.Tensor] = None
         self.index: Optional[IndexHandle] = None
 
     # ------------------------------------------------------------------ storage
@@ -352,14 +355,8 @@ class FAISSIndexBuilder:
             else:
                 self.last_search_path = "chained" if k > _native.SSKD_K_PASS else "single"
             scores, ids = self.search_device(qd, k, normalize_queries=normalize_queries)
-            if self.last_status is not None and int(self.last_status[0].item()) != 0:
-                # more unproven queries than the screened call's exact fallback holds: plain exact scan
-                self.screening, keep = False, self.screening
-                try:
-                    scores, ids = self.search_device(qd, k, normalize_queries=normalize_queries)
-                finally:
-                    self.screening = keep
-                self.last_search_path += "+exact-rerun"
+            if self.last_status is not None:
+                self.last_search_path += "+screened"
             return scores.cpu().numpy(), ids.cpu().numpy()
 
     def search(self, query_emb: np.ndarray, k: int = 10) -> Tuple[np.ndarray, np.ndarray]:

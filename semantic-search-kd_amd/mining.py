@@ -1,4 +1,11 @@
-"""ANCE hard-negative mining on the MI355X encoder + exact scan.
+"""Teacher (stage 2) and ANCE (stage 3) hard-negative mining on the MI355X teacher / encoder + exact scan.
+
+``TeacherMiner`` is the drop-in for the reference's class of that name (src/mining/miners.py:80-158): same
+constructor, same ``mine`` signature, same selection rule (stable descending sort by teacher score, the first
+``top_k``, then the confidence filter) - but ONE ``teacher.score`` call over the pairs of every query instead of
+one call of <= 100 pairs per query, so the GPU sees launches cut by a token budget, not by the query loop (and,
+after ``TeacherModel.data_parallel()``, pair ranges sharded over the process group).
+
 
 Drop-in for the reference's ``ANCEMiner`` (reference: src/mining/miners.py:160-253): same constructor,
 same ``mine`` signature and the same selection rule -
@@ -28,6 +35,41 @@ def select_adversarial(cand_ids: Sequence[str], cand_scores: np.ndarray, pos_sco
     adversarial = [(d, float(s)) for d, s in zip(cand_ids, cand_scores) if s >= max_pos - margin]
     adversarial.sort(key=lambda x: x[1], reverse=True)
     return [d for d, _ in adversarial[:top_k]]
+
+
+def select_confident(cand_ids: Sequence[str], scores: Sequence[float], get_confidence, threshold: float, top_k: int):
+    """The reference's rule (src/mining/miners.py:140-151): ``sorted(zip(ids, scores), key=score, reverse=True)`` is a
+    STABLE descending sort (equal scores keep candidate order), the first ``top_k`` survive, then those whose
+    confidence is below the threshold are dropped (so fewer than ``top_k`` may remain)."""
+    ranked = sorted(zip(cand_ids, scores), key=lambda x: x[1], reverse=True)
+    ids, kept = [], []
+    for doc_id, score in ranked[:top_k]:
+        if get_confidence(score) >= threshold:
+            ids.append(doc_id)
+            kept.append(score)
+    return ids, kept
+
+
+class TeacherMiner:
+    def __init__(self, teacher_model, confidence_threshold: float = 0.6):
+        self.teacher = teacher_model
+        self.confidence_threshold = confidence_threshold
+
+    def mine(self, queries: List[str], candidates: List[List[str]], candidate_texts: Dict[str, str], top_k: int = 10):
+        """``(hard_negative_ids, teacher_scores)``, one list per query (src/mining/miners.py:104-158).  A candidate id
+        missing from ``candidate_texts`` is scored against the empty text, as in the reference (:130)."""
+        pairs = [(q, candidate_texts.get(doc_id, "")) for q, cand_ids in zip(queries, candidates) for doc_id in cand_ids]
+        scores = list(self.teacher.score(pairs, batch_size=32)) if pairs else []
+        all_ids: List[List[str]] = []
+        all_scores: List[List[float]] = []
+        at = 0
+        for _, cand_ids in zip(queries, candidates):
+            part = scores[at : at + len(cand_ids)]
+            at += len(cand_ids)
+            ids, kept = select_confident(cand_ids, part, self.teacher.get_confidence, self.confidence_threshold, top_k)
+            all_ids.append(ids)
+            all_scores.append(kept)
+        return all_ids, all_scores
 
 
 class ANCEMiner:

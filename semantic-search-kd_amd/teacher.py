@@ -58,16 +58,67 @@ class TeacherConfig:
                           type_vocab_size=self.type_vocab_size, layer_norm_eps=self.layer_norm_eps)
 
 
-def synthetic_teacher_state_dict(cfg: TeacherConfig) -> Dict[str, np.ndarray]:
-    """Deterministic random-init weights (the recipe of weights.synthetic_state_dict) + classifier head."""
+def synthetic_teacher_state_dict(cfg: TeacherConfig, recipe: str = "init") -> Dict[str, np.ndarray]:
+    """Deterministic synthetic weights + classifier head.
+
+    ``recipe="init"``: the random-init recipe of weights.synthetic_state_dict (every matrix at std 0.02).  Such a
+    network barely mixes tokens - the <s> state, and with it the logit, is almost the same for every input.
+    ``recipe="spread"``: gains shaped like a TRAINED checkpoint's - value / output projections and the FFN at
+    unit gain (std 1 / sqrt(fan_in)) times 1.5 / 1.0, query / key at 1.5 / sqrt(H) (attention logits of O(2):
+    peaky but not one-hot), word embeddings at unit variance - so that attention moves the <s> state by as much as
+    the residual carries and the logits of different inputs spread over several units (std about 1.3).  This is
+    what the score-level parity tests use: an ORDER of logits that a broken kernel cannot reproduce.
+    """
     sd = synthetic_state_dict(cfg.as_bert())
-    h = cfg.hidden_size
-    # head scales chosen so that logits of different inputs differ at O(0.1 - 1) (a parity test needs that)
-    sd["classifier.dense.weight"] = synthetic_tensor("classifier.dense.weight", (h, h), 4.0 / math.sqrt(h))
+    h, f = cfg.hidden_size, cfg.intermediate_size
+    if recipe == "init":
+        # head scales chosen so that logits of different inputs differ at O(0.1 - 1)
+        sd["classifier.dense.weight"] = synthetic_tensor("classifier.dense.weight", (h, h), 4.0 / math.sqrt(h))
+        sd["classifier.dense.bias"] = synthetic_tensor("classifier.dense.bias", (h,), 0.1)
+        sd["classifier.out_proj.weight"] = synthetic_tensor("classifier.out_proj.weight", (1, h), 8.0 / math.sqrt(h))
+        sd["classifier.out_proj.bias"] = synthetic_tensor("classifier.out_proj.bias", (1,), 0.1)
+        return sd
+    if recipe != "spread":
+        raise ValueError(f"unknown weight recipe {recipe!r}")
+    u = math.sqrt(3.0)  # uniform(-s, s) has std s / sqrt(3)
+
+    def mat(name, shape, std):
+        return synthetic_tensor(name + "#spread", shape, std * u)
+
+    sd["embeddings.word_embeddings.weight"] = mat("embeddings.word_embeddings.weight", (cfg.vocab_size, h), 1.0)
+    sd["embeddings.position_embeddings.weight"] = mat("embeddings.position_embeddings.weight", (cfg.max_position_embeddings, h), 0.3)
+    for i in range(cfg.num_hidden_layers):
+        p = f"encoder.layer.{i}."
+        for nm, shape, std in (("attention.self.query", (h, h), 1.5 / math.sqrt(h)), ("attention.self.key", (h, h), 1.5 / math.sqrt(h)),
+                               ("attention.self.value", (h, h), 1.5 / math.sqrt(h)), ("attention.output.dense", (h, h), 1.5 / math.sqrt(h)),
+                               ("intermediate.dense", (f, h), 1.0 / math.sqrt(h)), ("output.dense", (h, f), 1.0 / math.sqrt(f))):
+            sd[p + nm + ".weight"] = mat(p + nm + ".weight", shape, std)
+    sd["classifier.dense.weight"] = mat("classifier.dense.weight", (h, h), 1.0 / math.sqrt(h))
     sd["classifier.dense.bias"] = synthetic_tensor("classifier.dense.bias", (h,), 0.1)
-    sd["classifier.out_proj.weight"] = synthetic_tensor("classifier.out_proj.weight", (1, h), 8.0 / math.sqrt(h))
+    sd["classifier.out_proj.weight"] = mat("classifier.out_proj.weight", (1, h), 2.0 / math.sqrt(h))
     sd["classifier.out_proj.bias"] = synthetic_tensor("classifier.out_proj.bias", (1,), 0.1)
     return sd
+
+
+def synthetic_pair_token_ids(cfg: TeacherConfig, n_pairs: int, width: int, seed: int, lengths=None):
+    """XLM-R pair sequences ``<s> q </s></s> d </s>`` of random token ids (4 .. vocab), right-padded:
+    ``(ids int32 [n, width], mask int32 [n, width])``.  Every pair draws its own tokens, so different inputs really
+    differ (the BERT-shaped ``synthetic_token_ids`` recipe clamps small vocabularies to ONE id)."""
+    rng = np.random.default_rng(seed)
+    if lengths is None:
+        lengths = rng.integers(min(8, width), width + 1, size=n_pairs)
+    ids = rng.integers(4, cfg.vocab_size, size=(n_pairs, width)).astype(np.int32)
+    mask = np.zeros((n_pairs, width), np.int32)
+    for b, n in enumerate(lengths):
+        n = int(min(max(n, 6), width))
+        mask[b, :n] = 1
+        ids[b, n:] = cfg.pad_token_id
+        ids[b, 0] = 0
+        q_len = max(1, min(n - 5, int(rng.integers(2, 12))))
+        ids[b, 1 + q_len] = 2
+        ids[b, 2 + q_len] = 2
+        ids[b, n - 1] = 2
+    return ids, mask
 
 
 class TeacherModel:
@@ -181,8 +232,9 @@ class TeacherModel:
         w.type_emb = bf(sd["embeddings.token_type_embeddings.weight"])
         w.emb_ln_g, w.emb_ln_b = f32(sd["embeddings.LayerNorm.weight"]), f32(sd["embeddings.LayerNorm.bias"])
         w.layers = layers
-        self._head = (bf(sd["classifier.dense.weight"]), f32(sd["classifier.dense.bias"]),
-                      bf(sd["classifier.out_proj.weight"]), f32(sd["classifier.out_proj.bias"]))
+        # the classification head stays fp32 end to end (a reranker's product is the ORDER of its logits)
+        self._head = (f32(sd["classifier.dense.weight"]), f32(sd["classifier.dense.bias"]),
+                      f32(sd["classifier.out_proj.weight"]), f32(sd["classifier.out_proj.bias"]))
         self._w, self._layers, self._keep = w, layers, keep
         self._cfg = _native.GenericConfig(cfg.vocab_size, cfg.hidden_size, L, cfg.num_attention_heads, cfg.intermediate_size,
                                           cfg.max_position_embeddings, cfg.type_vocab_size, float(cfg.layer_norm_eps),
@@ -229,26 +281,50 @@ class TeacherModel:
             mask[i, : len(r)] = 1
         return ids, mask
 
+    def data_parallel(self, enabled: bool = True, group=None) -> "TeacherModel":
+        """Shard ``score`` over the ranks of a ``torch.distributed`` process group (BASELINE cfg 5: one process per
+        GPU, each holding the full model): rank r scores the contiguous pair range ``shard_bounds(n, G, r)``, ONE
+        all-gather of the scores is the final concat, every rank returns all n scores (``dist.sharded_scores``).
+        Every rank must call ``score`` with the same pairs.  ``group=None`` = the default group."""
+        self._dp_enabled, self._dp_group = bool(enabled), group
+        return self
+
+    def _score_local(self, pairs) -> torch.Tensor:
+        """fp32 [n] device tensor of raw logits for this process's pairs: sorted by length, cut into launches by a
+        token budget, written in sorted order and un-permuted once at the end."""
+        n = len(pairs)
+        if n == 0:
+            return torch.empty(0, dtype=torch.float32, device=self.torch_device)
+        ids, mask = self.tokenize_pairs(pairs)
+        lengths = mask.sum(1)
+        order = np.argsort(-lengths, kind="stable")
+        ids, mask, lengths = ids[order], mask[order], lengths[order]
+        sorted_out = torch.empty(n, dtype=torch.float32, device=self.torch_device)
+        budget = 64 * 512
+        lo = 0
+        while lo < n:
+            width = max(int(lengths[lo]), 1)
+            rows = max(1, budget // (-(-width // 32) * 32))
+            self.score_token_ids(ids[lo : lo + rows, :width], mask[lo : lo + rows, :width], out=sorted_out[lo : lo + rows])
+            lo += rows
+        out = torch.empty_like(sorted_out)
+        out[torch.from_numpy(order).to(self.torch_device)] = sorted_out
+        return out
+
     def score(self, pairs: Sequence[Union[Tuple[str, str], List[str]]], batch_size: int = 32) -> List[float]:
         """``CrossEncoder.predict``-shaped: one float (raw logit) per (query, passage) pair.  Pairs are
         sorted by length and cut into launches by a token budget; ``batch_size`` (reference default 32)
-        does not shape the GPU work."""
+        does not shape the GPU work.  After ``data_parallel()`` the pairs are split over the process group."""
         del batch_size
         n = len(pairs)
         if n == 0:
             return []
-        ids, mask = self.tokenize_pairs(pairs)
-        lengths = mask.sum(1)
-        order = np.argsort(-lengths, kind="stable")
-        out = torch.empty(n, dtype=torch.float32, device=self.torch_device)
-        budget = 64 * 512
-        lo = 0
-        while lo < n:
-            width = max(int(lengths[order[lo]]), 1)
-            rows = max(1, budget // (-(-width // 32) * 32))
-            idx = order[lo : lo + rows]
-            out[torch.from_numpy(idx).to(self.torch_device)] = self.score_token_ids(ids[idx, :width], mask[idx, :width])
-            lo += rows
+        if getattr(self, "_dp_enabled", False):
+            from .dist import sharded_scores
+
+            out = sharded_scores(lambda lo, hi: self._score_local(pairs[lo:hi]), n, self._dp_group, self.torch_device)
+        else:
+            out = self._score_local(pairs)
         return [float(x) for x in out.cpu().numpy()]
 
     def predict_score(self, query: str, document: str) -> float:

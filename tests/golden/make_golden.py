@@ -291,6 +291,59 @@ def make_ance():
     print("[ance] reference ANCEMiner.mine:", {k: sum(len(x) for x in v) for k, v in out.items()}, "negatives")
 
 
+class HashedTeacher:
+    """Deterministic stand-in teacher for the mining fixture: a score that depends only on the (query, text) strings
+    (crc32 -> [-4, 4)), with duplicates of one candidate text giving exact score ties; ``get_confidence`` = sigmoid,
+    as the product's TeacherModel.  Records how ``score`` was called."""
+
+    def __init__(self):
+        self.calls = []
+
+    def score(self, pairs, batch_size=32):
+        import zlib
+
+        self.calls.append((len(pairs), batch_size))
+        return [((zlib.crc32((q + "\x00" + t).encode()) % 8000) / 1000.0) - 4.0 for q, t in pairs]
+
+    @staticmethod
+    def get_confidence(score):
+        import math
+
+        return 1.0 / (1.0 + math.exp(-float(score)))
+
+
+def teacher_mining_case():
+    queries, _, candidates, docs = ance_case()
+    docs = dict(docs)
+    docs["d11"] = docs["d12"]              # identical texts -> exact score ties: the stable sort decides
+    candidates = [list(c) for c in candidates]
+    candidates[1] = candidates[1] + ["d11", "d12"]
+    return queries, candidates, docs
+
+
+def make_teacher_mining():
+    """Hard negatives and scores chosen by the REFERENCE'S OWN ``TeacherMiner.mine`` (src/mining/miners.py:104-158)
+    for a deterministic stand-in teacher."""
+    import json
+    import types
+
+    _register_reference_stubs()
+    if "rank_bm25" not in sys.modules:
+        ph = types.ModuleType("rank_bm25")
+        ph.BM25Okapi = type("BM25Okapi", (), {})
+        sys.modules["rank_bm25"] = ph
+    from src.mining.miners import TeacherMiner as RefMiner
+
+    queries, candidates, docs = teacher_mining_case()
+    out = {}
+    for thr in (0.6, 0.5, 0.9):
+        for top_k in (10, 3):
+            ids, scores = RefMiner(HashedTeacher(), confidence_threshold=thr).mine(queries, candidates, docs, top_k=top_k)
+            out[f"thr{thr}_k{top_k}"] = {"ids": ids, "scores": scores}
+    (HERE / "teacher_mining.json").write_text(json.dumps(out, indent=0, sort_keys=True) + "\n")
+    print("[teacher_mining] reference TeacherMiner.mine:", {k: sum(len(x) for x in v["ids"]) for k, v in out.items()}, "negatives")
+
+
 def make_pool_norm():
     g = np.random.Generator(np.random.PCG64(7))
     h = g.standard_normal((8, 64, 384), dtype=np.float32)
@@ -422,15 +475,10 @@ def teacher_case():
     return cfg, sd, ids, mask
 
 
-def make_xlmr():
-    """Logits of ``transformers.XLMRobertaForSequenceClassification`` (num_labels = 1: the architecture
-    of the reference's bge-reranker-large teacher) built from an in-memory config on synthetic weights;
-    the oracle restatement (oracle/teacher.py) is asserted equal here."""
+def _xlmr_logits(cfg, sd, ids, mask):
+    """``transformers.XLMRobertaForSequenceClassification`` (one label) from an IN-MEMORY config + the given weights"""
     from transformers import XLMRobertaConfig, XLMRobertaForSequenceClassification
 
-    from oracle import teacher as teacher_oracle
-
-    cfg, sd, ids, mask = teacher_case()
     hf_cfg = XLMRobertaConfig(
         vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
         num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
@@ -444,11 +492,51 @@ def make_xlmr():
     assert not unexpected, unexpected
     assert all("position_ids" in m for m in missing), missing
     with torch.no_grad():
-        want = model(input_ids=torch.from_numpy(ids).long(), attention_mask=torch.from_numpy(mask).long()).logits[:, 0].numpy()
+        return model(input_ids=torch.from_numpy(ids).long(), attention_mask=torch.from_numpy(mask).long()).logits[:, 0].numpy()
+
+
+def make_xlmr():
+    """Logits of ``transformers.XLMRobertaForSequenceClassification`` (num_labels = 1: the architecture
+    of the reference's bge-reranker-large teacher) built from an in-memory config on synthetic weights;
+    the oracle restatement (oracle/teacher.py) is asserted equal here."""
+    from oracle import teacher as teacher_oracle
+
+    cfg, sd, ids, mask = teacher_case()
+    want = _xlmr_logits(cfg, sd, ids, mask)
     got = teacher_oracle.logits(sd, ids, mask, cfg.num_hidden_layers, cfg.num_attention_heads, cfg.layer_norm_eps, cfg.pad_token_id)
     print(f"[xlmr_small] oracle vs transformers logits: max |diff| = {np.abs(got - want).max():.3e}; logits {want}")
     assert np.abs(got - want).max() < 1e-5
     np.savez_compressed(HERE / "xlmr_small.npz", input_ids=ids, attention_mask=mask, logits=want)
+
+
+TEACHER_SPREAD = dict(vocab_size=800, hidden_size=128, num_hidden_layers=4, num_attention_heads=4, intermediate_size=512,
+                      max_position_embeddings=130)
+
+
+def teacher_spread_case():
+    """The DISCRIMINATING teacher fixture: 40 pair sequences of distinct random tokens, ragged lengths,
+    weights of the "spread" recipe (trained-like gains), so the fp32 logits spread over several units and their ORDER
+    is something a kernel has to get right."""
+    from semantic_search_kd_amd.teacher import TeacherConfig, synthetic_pair_token_ids, synthetic_teacher_state_dict
+
+    cfg = TeacherConfig(**TEACHER_SPREAD)
+    sd = synthetic_teacher_state_dict(cfg, recipe="spread")
+    ids, mask = synthetic_pair_token_ids(cfg, 40, 96, seed=53)
+    return cfg, sd, ids, mask
+
+
+def make_xlmr_spread():
+    from oracle import teacher as teacher_oracle
+
+    cfg, sd, ids, mask = teacher_spread_case()
+    want = _xlmr_logits(cfg, sd, ids, mask)
+    got = teacher_oracle.logits(sd, ids, mask, cfg.num_hidden_layers, cfg.num_attention_heads, cfg.layer_norm_eps, cfg.pad_token_id)
+    spread = float(want.max() - want.min())
+    gaps = np.diff(np.sort(want))
+    print(f"[xlmr_spread] oracle vs transformers: max |diff| = {np.abs(got - want).max():.3e}; {len(want)} logits, spread "
+          f"{spread:.3f}, std {want.std():.3f}, smallest gap between neighbours {gaps.min():.4f}")
+    assert np.abs(got - want).max() < 2e-5 and spread >= 2.0 and len(want) >= 32
+    np.savez_compressed(HERE / "xlmr_spread.npz", input_ids=ids, attention_mask=mask, logits=want)
 
 
 def make_kd_loss():
@@ -542,18 +630,16 @@ def make_api_schemas():
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    make_search_small()
-    make_search_1k()
-    make_search_ref()
-    make_pool_norm()
-    make_bert(2, "l2")
-    make_bert(12, "l12")
-    make_bert(2, "stress_l2", stress=True)
-    make_bert(12, "stress_l12", stress=True)
-    make_bert_grads()
-    make_xlmr()
-    make_kd_loss()
-    make_ance()
-    make_api_schemas()
+    steps = {
+        "search_small": make_search_small, "search_1k": make_search_1k, "search_ref": make_search_ref,
+        "pool_norm": make_pool_norm, "bert_l2": lambda: make_bert(2, "l2"), "bert_l12": lambda: make_bert(12, "l12"),
+        "bert_stress_l2": lambda: make_bert(2, "stress_l2", stress=True),
+        "bert_stress_l12": lambda: make_bert(12, "stress_l12", stress=True), "bert_grads": make_bert_grads,
+        "xlmr": make_xlmr, "xlmr_spread": make_xlmr_spread, "kd_loss": make_kd_loss, "ance": make_ance,
+        "teacher_mining": make_teacher_mining, "api_schemas": make_api_schemas,
+    }
+    wanted = sys.argv[1:] or list(steps)   # ``python make_golden.py xlmr_spread`` regenerates one fixture
+    for name in wanted:
+        steps[name]()
     for p in sorted(HERE.glob("*.npz")):
         print(f"{p.name}: {p.stat().st_size / 1024:.1f} KiB")

@@ -264,6 +264,37 @@ def test_ance_miner_matches_reference_fixture():
     assert ANCEMiner(HashedEmbeddingStudent()).mine([], [], [], {}, {}) == []
 
 
+def test_teacher_miner_matches_reference_fixture():
+    """tests/golden/teacher_mining.json holds ids AND scores chosen by the REFERENCE'S OWN TeacherMiner.mine
+    (src/mining/miners.py:104-158) for a deterministic stand-in teacher (make_golden.make_teacher_mining): the
+    batched drop-in must return the same ids in the same order with the same scores - including the stable order
+    of exact score ties, ids missing from the text table, empty candidate lists and the confidence filter - while
+    calling ``teacher.score`` ONCE for all queries (the reference: once per query)."""
+    import json
+    import sys
+
+    from conftest import GOLDEN
+
+    sys.path.insert(0, str(GOLDEN))
+    from make_golden import HashedTeacher, teacher_mining_case
+
+    from semantic_search_kd_amd.mining import TeacherMiner
+
+    gold = json.loads((GOLDEN / "teacher_mining.json").read_text())
+    queries, candidates, docs = teacher_mining_case()
+    assert gold["thr0.9_k10"] != gold["thr0.5_k10"] and any(len(x) < 3 for x in gold["thr0.9_k3"]["ids"])
+    for thr in (0.6, 0.5, 0.9):
+        for top_k in (10, 3):
+            teacher = HashedTeacher()
+            ids, scores = TeacherMiner(teacher, confidence_threshold=thr).mine(queries, candidates, docs, top_k=top_k)
+            want = gold[f"thr{thr}_k{top_k}"]
+            assert ids == want["ids"], (thr, top_k)
+            assert scores == want["scores"], (thr, top_k)
+            assert teacher.calls == [(sum(len(c) for c in candidates), 32)]
+    assert TeacherMiner(HashedTeacher()).mine([], [], {}) == ([], [])
+    assert TeacherMiner(HashedTeacher()).mine(["q"], [[]], {}) == ([[]], [[]])
+
+
 def test_screened_search_launch_plan_is_sane_across_shapes():
     """The screening launch plan is a host function of the shape (no GPU needed): every served shape gets a
     positive workspace, 64 or 128 queries per workgroup, at least one slice, and never more workgroups in

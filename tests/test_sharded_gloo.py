@@ -74,7 +74,49 @@ def test_sharded_search_equals_unsharded(tmp_path, n, nq, k, world):
         assert np.array_equal(got["i"], ref_i) and np.array_equal(got["s"], ref_s)
 
 
-def _gpu_worker(rank, world, port, n, nq, k, out_dir, backend):
+def _score_worker(rank, world, port, n, out_dir):
+    """teacher-style data parallelism (cfg 5): contiguous item ranges, ONE all-gather as the final concat"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from semantic_search_kd_amd.dist import sharded_scores
+
+        calls = []
+
+        def score(lo, hi):
+            calls.append((lo, hi))
+            return torch.arange(lo, hi, dtype=torch.float32) * 0.5 - 3.0
+
+        out = sharded_scores(score, n)
+        assert calls == ([shard_bounds(n, world, rank)] if shard_bounds(n, world, rank)[1] > shard_bounds(n, world, rank)[0] else [])
+        np.save(os.path.join(out_dir, f"scores{rank}.npy"), out.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,world", [(1000, 2), (7, 2), (1, 2), (10, 4), (3, 4)])
+def test_sharded_scores_concat_equals_unsharded(tmp_path, n, world):
+    mp.spawn(_score_worker, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    want = np.arange(n, dtype=np.float32) * 0.5 - 3.0
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"scores{r}.npy"), want)
+
+
+def _sharded_case(n, nq, dups):
+    """Seeded rows / queries; ``dups``: 64 copies of one row inside EACH shard and every query next to it -
+    more than 1 024 queries per rank whose candidate band cannot be proven (round 2: such rows came back
+    poisoned from ``search_device`` and were merged silently; now the call answers them itself)."""
+    corpus = oracle.seeded_unit_rows(n, 384, 1234)
+    queries = oracle.seeded_unit_rows(nq, 384, 4321)
+    if dups:
+        corpus[1000:1064] = corpus[5]
+        corpus[n // 2 + 700 : n // 2 + 764] = corpus[5]
+        queries = np.repeat(corpus[5][None], nq, axis=0) + 0.01 * queries
+        queries = (queries / np.linalg.norm(queries, axis=1, keepdims=True)).astype(np.float32)
+    return corpus, queries
+
+
+def _gpu_worker(rank, world, port, n, nq, k, out_dir, backend, dups=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     dev = torch.device("cuda", rank if backend == "nccl" else 0)
     torch.cuda.set_device(dev)
@@ -85,8 +127,8 @@ def _gpu_worker(rank, world, port, n, nq, k, out_dir, backend):
     try:
         from semantic_search_kd_amd import FAISSIndexBuilder
 
-        corpus = oracle.seeded_unit_rows(n, 384, 1234)
-        queries = torch.from_numpy(oracle.seeded_unit_rows(nq, 384, 4321)).to(dev)
+        corpus, queries = _sharded_case(n, nq, dups)
+        queries = torch.from_numpy(queries).to(dev)
         lo, hi = shard_bounds(n, world, rank)
         index = FAISSIndexBuilder(embedding_dim=384, metric="ip", device=str(dev), id_offset=lo)
         index.add(corpus[lo:hi])
@@ -103,31 +145,35 @@ def _gpu_worker(rank, world, port, n, nq, k, out_dir, backend):
         s, i = searcher.search(queries, k)
         torch.cuda.synchronize()
         assert searcher.last_world == world
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), s=s.cpu().numpy(), i=i.cpu().numpy())
+        fallback = -1 if index.last_status is None else int(index.last_status[1])
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), s=s.cpu().numpy(), i=i.cpu().numpy(), fallback=fallback)
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,nq,k", [(5000, 70, 10), (5, 3, 10)])
-def test_product_sharded_search_two_ranks(tmp_path, n, nq, k):
-    """search_device -> packed record -> all-gather -> sskd_topk_merge_packed in 2 processes."""
+@pytest.mark.parametrize("n,nq,k,dups", [(5000, 70, 10, False), (5, 3, 10, False), (8192, 1200, 10, True)])
+def test_product_sharded_search_two_ranks(tmp_path, n, nq, k, dups):
+    """search_device -> packed record -> all-gather -> sskd_topk_merge_packed in 2 processes; the third case
+    drives > 1 024 queries per rank through the screened search's in-call exact fallback (duplicate-heavy
+    shards): the merged result must still be the oracle's, bit for bit."""
     backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
     world = 2
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_gpu_worker, args=(r, world, _PORTS.setdefault((n, nq), _free_port()), n, nq, k, str(tmp_path), backend))
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, _PORTS.setdefault((n, nq), _free_port()), n, nq, k, str(tmp_path), backend, dups))
              for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(timeout=300)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-    corpus = oracle.seeded_unit_rows(n, 384, 1234)
-    queries = oracle.seeded_unit_rows(nq, 384, 4321)
+    corpus, queries = _sharded_case(n, nq, dups)
     ref_s, ref_i = oracle.topk_fma(queries, corpus, k)
     for r in range(world):
         got = np.load(tmp_path / f"rank{r}.npz")
         assert np.array_equal(got["i"], ref_i) and np.array_equal(got["s"], ref_s)
+        if dups:
+            assert int(got["fallback"]) > 1024, int(got["fallback"])   # the regime that used to poison rows
 
 
 _PORTS = {}
