@@ -160,6 +160,13 @@ class ShardedSearcher:
         recv = torch.empty(world * rec, dtype=torch.uint8, device=dev)
         if self.all_gather is not None:
             self.all_gather(recv, send)
+        elif dist.get_backend(self.group) == "gloo" and send.is_cuda:
+            # gloo moves host memory (several ranks sharing one GPU in tests, CPU-only rehearsals): stage the
+            # 12-byte-per-result records through the host.  On a node with one GPU per rank the backend is nccl
+            # (= RCCL over xGMI) and the records never leave HBM.
+            host = torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_gather_into_tensor(host, send.cpu(), group=self.group)
+            recv.copy_(host)
         else:
             dist.all_gather_into_tensor(recv, send, group=self.group)
         if self.merge is not None:

@@ -79,6 +79,7 @@ class FAISSIndexBuilder:
         self.doc_ids: List[str] = []
         self.doc_texts: Optional[dict] = None
         self.id_offset = int(id_offset)  # global id of local row 0 (row-sharded corpora)
+        self.shard_info: Optional[dict] = None  # {"rank", "world_size", "n_total"} when written by build_sharded
         self._tiled: Optional[torch.Tensor] = None  # fp32 [capacity_rows * 384], tiled layout
         self._n = 0
         self._workspace: Optional[torch.Tensor] = None
@@ -199,19 +200,8 @@ class FAISSIndexBuilder:
         tests/conftest.py:210-216): ``text`` and ``chunk_id``.  ``hnsw_*`` are accepted for
         CLI compatibility (scripts/build_faiss_index.py:59-61); an exact scan has no graph.
         """
-        import pandas as pd
-
         del hnsw_m, hnsw_ef_construction
-        df = pd.read_parquet(parquet_path)
-        if max_docs is not None:
-            df = df.head(max_docs)
-        if text_column not in df.columns:
-            raise KeyError(f"parquet file {parquet_path} has no {text_column!r} column")
-        texts = df[text_column].astype(str).tolist()
-        if id_column in df.columns:
-            ids = df[id_column].astype(str).tolist()
-        else:
-            ids = [f"doc_{i}" for i in range(len(texts))]
+        ids, texts = read_corpus_parquet(parquet_path, max_docs, text_column, id_column)
         self._n = 0
         self._tiled = None
         self.reserve(len(texts))
@@ -388,7 +378,9 @@ class FAISSIndexBuilder:
         return out.cpu().numpy()
 
     def save(self, output_dir: Union[str, Path]) -> None:
-        """Write ``index.faiss`` (flat inner-product layout) + ``doc_ids.json`` (+ ``texts.json``)."""
+        """Write ``index.faiss`` (flat inner-product layout) + ``doc_ids.json`` (+ ``texts.json``).  A row shard
+        (``id_offset != 0``, or one written by ``sharded_index.build_sharded``) also gets ``shard.json`` with the
+        global id of its first row, which ``load`` restores."""
         out = Path(output_dir)
         out.mkdir(parents=True, exist_ok=True)
         write_flat_ip(out / "index.faiss", self.to_numpy())
@@ -397,8 +389,13 @@ class FAISSIndexBuilder:
         if self.doc_texts is not None:
             with open(out / "texts.json", "w") as f:
                 json.dump(self.doc_texts, f)
+        if self.id_offset != 0 or self.shard_info:
+            with open(out / "shard.json", "w") as f:
+                json.dump({**(self.shard_info or {}), "id_offset": self.id_offset, "rows": self._n}, f)
 
-    def load(self, index_dir: Union[str, Path]) -> None:
+    def load(self, index_dir: Union[str, Path], append: bool = False) -> None:
+        """Restore a saved index (``append=True``: add its rows behind the ones already held - consecutive row
+        shards served by one process).  ``shard.json``, when present, restores ``id_offset``."""
         d = Path(index_dir)
         path = d / "index.faiss"
         if not path.exists():
@@ -406,11 +403,22 @@ class FAISSIndexBuilder:
         vecs = read_flat_ip(path)
         if vecs.shape[1] != self.embedding_dim:
             raise ValueError(f"index has dim {vecs.shape[1]}, builder expects {self.embedding_dim}")
+        shard_path = d / "shard.json"
+        shard = json.loads(shard_path.read_text()) if shard_path.exists() else None
         metric, self.metric = self.metric, "ip"  # stored vectors are already normalised
         try:
-            self._n = 0
-            self._tiled = None
-            self.reserve(vecs.shape[0])
+            if not append:
+                self._n = 0
+                self._tiled = None
+                self.doc_ids = []
+                self.doc_texts = None
+                if shard is not None:
+                    self.id_offset = int(shard["id_offset"])
+                    self.shard_info = {k: v for k, v in shard.items() if k not in ("id_offset", "rows")}
+            elif shard is not None and int(shard["id_offset"]) != self.id_offset + self._n:
+                raise ValueError(f"{d}: shard starts at row {shard['id_offset']}, expected {self.id_offset + self._n}")
+            first = self._n
+            self.reserve(self._n + vecs.shape[0])
             step = 1 << 18  # stream the (memory-mapped) matrix in 400 MB slabs
             for lo in range(0, vecs.shape[0], step):
                 self.add(np.array(vecs[lo : lo + step], dtype=np.float32, copy=True))
@@ -419,9 +427,13 @@ class FAISSIndexBuilder:
         ids_path = d / "doc_ids.json"
         if ids_path.exists():
             with open(ids_path) as f:
-                self.doc_ids = list(json.load(f))
+                self.doc_ids = list(self.doc_ids) + list(json.load(f))
         else:
-            self.doc_ids = [f"doc_{i}" for i in range(self._n)]
+            self.doc_ids = list(self.doc_ids) + [f"doc_{self.id_offset + i}" for i in range(first, self._n)]
+        texts_path = d / "texts.json"
+        if texts_path.exists():
+            with open(texts_path) as f:
+                self.doc_texts = {**(self.doc_texts or {}), **json.load(f)}
         self.index = IndexHandle(self)
 
     def cleanup(self) -> None:
@@ -431,6 +443,24 @@ class FAISSIndexBuilder:
 
 
 # ---------------------------------------------------------------------- helpers
+def read_corpus_parquet(parquet_path, max_docs: Optional[int] = None, text_column: str = "text",
+                        id_column: str = "chunk_id") -> Tuple[List[str], List[str]]:
+    """``(ids, texts)`` of a corpus in the reference's schema (src/data/prepare.py:72-84, tests/conftest.py:210-216)."""
+    import pandas as pd
+
+    df = pd.read_parquet(parquet_path)
+    if max_docs is not None:
+        df = df.head(max_docs)
+    if text_column not in df.columns:
+        raise KeyError(f"parquet file {parquet_path} has no {text_column!r} column")
+    texts = df[text_column].astype(str).tolist()
+    if id_column in df.columns:
+        ids = df[id_column].astype(str).tolist()
+    else:
+        ids = [f"doc_{i}" for i in range(len(texts))]
+    return ids, texts
+
+
 def _resolve_device(device: Optional[str]) -> torch.device:
     if device is None or device == "cuda":
         return torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)

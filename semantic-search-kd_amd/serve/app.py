@@ -25,7 +25,8 @@ from fastapi.responses import JSONResponse
 
 logger = logging.getLogger("semantic_search_kd_amd.serve")
 
-from ..index import FAISSIndexBuilder  # noqa: E402
+from ..index import FAISSIndexBuilder  # noqa: E402,F401
+from ..sharded_index import open_index
 from ..student import StudentModel
 from .schemas import (
     EncodeRequest,
@@ -85,14 +86,17 @@ app_state = AppState()
 
 
 def _load_index_dir(index_dir: Path) -> Dict[str, Any]:
-    builder = FAISSIndexBuilder(embedding_dim=app_state.student.embedding_dim)
-    builder.load(index_dir)
+    # a directory with a shards.json manifest opens as a row-sharded index (sharded_index.ShardedIndex: same
+    # search / doc_ids surface, answered by every rank of the process group); anything else as one FAISSIndexBuilder
+    builder = open_index(index_dir, app_state.student.embedding_dim, current=app_state.index_builder)
     app_state.index_builder = builder
     app_state.doc_ids = builder.doc_ids
     texts_path = index_dir / "texts.json"
     if texts_path.exists():
         with open(texts_path) as f:
             app_state.doc_texts = json.load(f)
+    elif builder.doc_texts:
+        app_state.doc_texts = builder.doc_texts
     return {"status": "loaded", "index_path": str(index_dir), "num_documents": len(app_state.doc_ids)}
 
 

@@ -152,7 +152,7 @@ def test_teacher_full_depth_24_layers_vs_oracle(gpu):
     tau = _kendall_tau(got, want)
     print(f"24 layers: min cos {cos.min():.5f}; logits max |d| = {err:.4f} = {100 * err / spread:.2f} % of the spread "
           f"{spread:.3f}; tau = {tau:.3f}")
-    assert cos.min() >= 0.998, cos.min()   # 24 layers of bf16 activations: 0.999 is the 2-layer gate
+    assert cos.min() >= 0.999, cos.min()   # measured 0.99976 (gpurun_out/r03_t2.log): the 2-layer gate holds at depth 24
     assert spread >= 1.5 and err <= SPREAD_REL_TOL * spread, (err, spread)
     # pairs whose fp32 logits differ by more than twice the observed error must keep their order
     for i in range(B):
