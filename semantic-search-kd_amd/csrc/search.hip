@@ -867,7 +867,11 @@ __device__ inline void compute_bgroup(const sbf16x8 (&a)[BGROUP], const sbf16x8*
   for (int s = 0; s < BGROUP; ++s) {
 #pragma unroll
     for (int qq = 0; qq < QB; ++qq) {
+#ifdef SSKD_SCREEN_ABL_NOLDS   // timing ablation (tools/ab_search.py, AB_NOCHECK): no LDS query-fragment reads
+      const sbf16x8 b = a[(s + qq) % BGROUP];
+#else
       const sbf16x8 b = qlane[(qq * BSTEPS + G * BGROUP + s) * 64];
+#endif
       acc[qq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b, acc[qq], 0, 0, 0);
     }
   }
@@ -881,8 +885,10 @@ __device__ inline void screen_tile_groups(sbf16x8 (&buf)[SCREEN_RING][BGROUP], c
                                           int64_t next_tile) {
   if constexpr (G < BGROUPS) {
     constexpr int PG = G + SCREEN_RING - 1;  // group to prefetch now
+#ifndef SSKD_SCREEN_ABL_NOGLOBAL  // timing ablation: no corpus tile loads (the ring keeps its first contents)
     if constexpr (PG < BGROUPS) load_bgroup(buf[PG % SCREEN_RING], tile + PG * BGROUP * 64);
     else if (more) load_bgroup(buf[PG % SCREEN_RING], tile + next_tile + (PG - BGROUPS) * BGROUP * 64);
+#endif
     compute_bgroup<QB, G>(buf[G % SCREEN_RING], qlane, acc);
     screen_tile_groups<QB, G + 1>(buf, tile, qlane, acc, more, next_tile);
   }
@@ -996,6 +1002,13 @@ __global__ __launch_bounds__(WAVES * 64) void screen_topk_kernel(ScreenParams p)
         for (int r = 0; r < 16; ++r)
           if (rowbase + (r & 3) + 8 * (r >> 2) >= p.n_rows) acc[qq][r] = -INFINITY;
     }
+#ifdef SSKD_SCREEN_ABL_NOLIST  // timing ablation: no list / pool maintenance (accumulators kept alive)
+#pragma unroll
+    for (int qq = 0; qq < QB; ++qq)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[qq][r]));
+    if (false)
+#endif
 #pragma unroll
     for (int qq = 0; qq < QB; ++qq) {
       float m = acc[qq][0];

@@ -202,7 +202,8 @@ def _gpu_worker(rank, world, port, tmp):
                             **({"device_id": torch.device(dev)} if multi else {}))
     try:
         out = Path(tmp) / "gpu_index"
-        build_sharded(SeededModel(), _corpus(Path(tmp)), out, batch_size=16, device=dev)
+        # metric "ip": rows and queries are used as given (no re-normalisation), so the oracle sees the same bits
+        build_sharded(SeededModel(), _corpus(Path(tmp)), out, batch_size=16, device=dev, metric="ip")
         index = ShardedIndex(device=dev)
         index.load_all_ranks(out)
         assert index.local.id_offset == shard_bounds(N_DOCS, world, rank)[0]
@@ -244,7 +245,7 @@ def test_sharded_build_reload_serve_two_ranks_gpu(gpu, tmp_path):
     # a shard directory alone is a FAISSIndexBuilder.load target that keeps its global ids
     from semantic_search_kd_amd import FAISSIndexBuilder
 
-    b = FAISSIndexBuilder(embedding_dim=384)
+    b = FAISSIndexBuilder(embedding_dim=384, metric="ip")
     b.load(tmp_path / "gpu_index" / "shard_1")
     lo, hi = shard_bounds(N_DOCS, 2, 1)
     assert b.id_offset == lo and b.ntotal == hi - lo
