@@ -62,21 +62,44 @@ class HipEvents:
         return float(ms.value)
 
 
-def cpu_search_baseline(corpus_host: np.ndarray, queries_host: np.ndarray, k: int, budget_s: float = 20.0):
-    """The reference's CPU exact-search idiom on the box's host cores (kind "port"):
-    ``np.matmul(q, corpus.T)`` + top-k by argsort (scripts/simple_eval.py:25,35), chunked over
-    the corpus so the score matrix stays small.  Bounded sample: as many 100-query batches as
-    fit ~budget_s."""
+def physical_cores() -> int:
+    """Physical cores this process may use (the CPU baselines run one BLAS / OpenMP thread per core)."""
+    try:
+        import psutil
+
+        phys = psutil.cpu_count(logical=False) or 0
+    except Exception:
+        phys = 0
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except Exception:
+        allowed = os.cpu_count() or 1
+    phys = phys or allowed
+    return max(1, min(phys, allowed))
+
+
+def cpu_search_baseline(n_rows: int, n_queries: int, k: int, budget_s: float = 20.0):
+    """The reference's CPU exact-search idiom on the box's host cores (kind "port"): ONE ``np.matmul`` over a whole
+    block of queries, as scripts/simple_eval.py:25 multiplies all its queries at once, then top-k
+    (argpartition + sort of the k survivors instead of the reference's full argsort of 10^6 scores per query,
+    scripts/simple_eval.py:35 - the baseline is not made slower than it has to be).  Synthetic unit rows of
+    the GPU leg's shape, drawn on the host.  Bounded sample: as many 1 024-query blocks as fit ~budget_s."""
     from oracle import search as oracle  # checker / baseline leg only
 
+    rng = np.random.default_rng(1234)
+    corpus = rng.standard_normal((n_rows, DIM), dtype=np.float32)
+    corpus /= np.linalg.norm(corpus, axis=1, keepdims=True)
+    queries = rng.standard_normal((min(n_queries, 8192), DIM), dtype=np.float32)
+    queries /= np.linalg.norm(queries, axis=1, keepdims=True)
+    oracle.scores_blas(queries[:64], corpus[:4096])   # BLAS thread pool up before the clock starts
     done, t0 = 0, time.perf_counter()
-    batch = 100
-    while done < queries_host.shape[0]:
-        q = queries_host[done : done + batch]
+    batch, chunk = 1024, 131072
+    while done < queries.shape[0]:
+        q = queries[done : done + batch]
         best_s = np.full((q.shape[0], k), -np.inf, np.float32)
         best_i = np.full((q.shape[0], k), -1, np.int64)
-        for lo in range(0, corpus_host.shape[0], 131072):
-            s = oracle.scores_blas(q, corpus_host[lo : lo + 131072])
+        for lo in range(0, n_rows, chunk):
+            s = oracle.scores_blas(q, corpus[lo : lo + chunk])
             part = np.argpartition(-s, k - 1, axis=1)[:, :k]
             cand_s = np.concatenate([best_s, np.take_along_axis(s, part, axis=1)], axis=1)
             cand_i = np.concatenate([best_i, part + lo], axis=1)
@@ -141,9 +164,12 @@ def cpu_encode_baseline(batch: int = 32, seq_len: int = 256, max_docs: int = 100
             break
     dt = time.perf_counter() - t0
     assert np.isfinite(e).all()
+    from semantic_search_kd_amd.bench_support import encoder_flops
+
     return {
         "value": round(done / dt, 2),
         "unit": "docs/s",
+        "gflops": round(encoder_flops(done * seq_len, seq_len, cfg) / dt / 1e9, 1),
         "cores": torch.get_num_threads(),
         "kind": "reference" if model is not None else "port",
         "sample": f"{done} passages of {seq_len} tokens in batches of {batch} ({engine}, fp32, the GPU leg's "
@@ -159,6 +185,196 @@ def faiss_probe() -> str:
     return "available" if importlib.util.find_spec("faiss") is not None else \
         "faiss not installed on this box: the reference's IndexHNSWFlat path cannot be timed; " \
         "cpu_baseline is the exact IndexFlatIP idiom (numpy sgemm + top-k)"
+
+
+def cpu_baselines_child() -> None:
+    """``bench.py --cpu-baseline-child``: both CPU baselines in a FRESH process that never touches the GPU, one
+    thread per physical core (set before NumPy / torch start their pools), printed as one JSON line."""
+    cores = physical_cores()
+    torch.set_num_threads(cores)
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cpu-baseline-child", action="store_true")
+    ap.add_argument("--corpus", type=int, default=N_CORPUS)
+    ap.add_argument("--queries", type=int, default=N_QUERIES)
+    ap.add_argument("--no-encode", action="store_true")
+    args, _ = ap.parse_known_args()
+    out = {}
+    qps, cpu_nq, cpu_dt = cpu_search_baseline(args.corpus, args.queries, K)
+    threads = cores
+    try:
+        from threadpoolctl import threadpool_info
+
+        blas = [p["num_threads"] for p in threadpool_info() if p.get("user_api") == "blas"]
+        threads = max(blas) if blas else threads
+    except Exception:
+        pass
+    out["search"] = {
+        "value": round(qps, 2),
+        "unit": "queries/s",
+        "gflops": round(2.0 * qps * args.corpus * DIM / 1e9, 1),
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{cpu_nq} queries in blocks of 1024 against a {args.corpus}-row synthetic corpus (one numpy sgemm per "
+                  f"block and 131072-row slab + argpartition: the reference's exact-search idiom, scripts/simple_eval.py:25,35), "
+                  f"{cpu_dt:.1f} s, fresh process before any GPU work",
+        "host_cpus": os.cpu_count(),
+        "physical_cores": cores,
+        "faiss_hnsw": faiss_probe(),
+    }
+    if not args.no_encode:
+        out["encode"] = cpu_encode_baseline()
+        out["encode"]["physical_cores"] = cores
+    print("CPU_BASELINES " + json.dumps(out), flush=True)
+
+
+def run_cpu_baselines_first(args) -> dict:
+    """Start the child BEFORE this process initialises the GPU (so no GPU-leg thread pool competes with it and none
+    of its own pools linger into the GPU legs) and wait for it: 30-40 s."""
+    import subprocess
+
+    cores = physical_cores()
+    env = dict(os.environ)
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        env[var] = str(cores)
+    cmd = [sys.executable, str(Path(__file__).resolve()), "--cpu-baseline-child", "--corpus", str(args.corpus),
+           "--queries", str(args.queries)] + (["--no-encode"] if args.no_encode else [])
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        for ln in r.stdout.splitlines():
+            if ln.startswith("CPU_BASELINES "):
+                return json.loads(ln[len("CPU_BASELINES "):])
+        return {"error": (r.stderr or r.stdout)[-400:]}
+    except Exception as exc:  # noqa: BLE001
+        return {"error": repr(exc)}
+
+
+def search_hip_sha() -> str:
+    import hashlib
+
+    return hashlib.sha256((REPO / "semantic-search-kd_amd" / "csrc" / "search.hip").read_bytes()).hexdigest()[:16]
+
+
+def _time_search(index, queries, k, steps, ev, lib, n_local, id_offset, screened: bool):
+    """(ms per call, kernel ms from HIP events around the dominant kernel, status) of the device-resident search"""
+    from semantic_search_kd_amd import _native
+
+    dev = queries.device
+    nq = queries.shape[0]
+    out_s = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    out_i = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    status = torch.zeros(2, dtype=torch.int32, device=dev)
+    st_ptr = int(torch.cuda.current_stream(dev).cuda_stream)
+    if screened:
+        index.search_device(queries[:64], k, normalize_queries=False)   # builds the screening sidecar
+        ws = torch.empty(int(lib.sskd_index_search_screened_workspace_bytes(n_local, nq, k)), dtype=torch.uint8, device=dev)
+    else:
+        ws = torch.empty(int(lib.sskd_index_search_workspace_bytes(n_local, nq, k)), dtype=torch.uint8, device=dev)
+    pairs = [(ev.create(), ev.create()) for _ in range(steps)]
+
+    def call(a, b):
+        if screened:
+            _native.check(lib.sskd_index_search_screened(index._tiled.data_ptr(), index._bf16.data_ptr(), n_local, queries.data_ptr(),
+                                                         nq, k, id_offset, out_s.data_ptr(), out_i.data_ptr(), status.data_ptr(),
+                                                         ws.data_ptr(), ws.numel(), st_ptr, a, b))
+        else:
+            _native.check(lib.sskd_index_search_profiled(index._tiled.data_ptr(), n_local, queries.data_ptr(), nq, k, id_offset,
+                                                         out_s.data_ptr(), out_i.data_ptr(), ws.data_ptr(), ws.numel(), st_ptr, a, b))
+
+    call(None, None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for a, b in pairs:
+        call(a, b)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    kernel_ms = float(np.mean([ev.elapsed_ms(a, b) for a, b in pairs]))
+    return ms, kernel_ms, status.cpu().numpy(), out_s, out_i
+
+
+def bench_search_anisotropic(pkg, lib, dev, n, nq, ev, steps: int = 5):
+    """The search on HOSTILE data instead of isotropic random unit vectors: e5-like geometry (a common component
+    that puts the mean pairwise cosine at 0.8), 64 topical clusters, 1 % near-duplicate rows, and a fifth of the
+    queries planted next to corpus rows.  Reports queries/s, how many queries needed the in-call exact fallback,
+    and that every output row equals the exact scan's (all queries, bit for bit)."""
+    g = torch.Generator(device=dev).manual_seed(99)
+    common = torch.nn.functional.normalize(torch.randn(DIM, generator=g, device=dev), dim=0)
+    centres = torch.randn((64, DIM), generator=g, device=dev) / DIM ** 0.5
+    index = pkg.FAISSIndexBuilder(embedding_dim=DIM, index_type="HNSW", metric="ip", device=str(dev))
+    index.reserve(n)
+    first = None
+    for lo in range(0, n, 1 << 18):
+        m = min(1 << 18, n - lo)
+        rows = 2.0 * common + 0.5 * centres[torch.randint(0, 64, (m,), generator=g, device=dev)] \
+            + torch.randn((m, DIM), generator=g, device=dev) / DIM ** 0.5
+        nd = m // 100   # near-duplicates: a copy of another row of the block + 1 % noise
+        src = torch.randint(0, m, (nd,), generator=g, device=dev)
+        dst = torch.randint(0, m, (nd,), generator=g, device=dev)
+        rows[dst] = rows[src] + 0.01 * torch.randn((nd, DIM), generator=g, device=dev) / DIM ** 0.5
+        rows = torch.nn.functional.normalize(rows, dim=1)
+        if first is None:
+            first = rows[:4096].clone()
+        index.add(rows)
+    q = 2.0 * common + 0.5 * centres[torch.randint(0, 64, (nq,), generator=g, device=dev)] \
+        + torch.randn((nq, DIM), generator=g, device=dev) / DIM ** 0.5
+    planted = q[::5].shape[0]
+    q[::5] = first[torch.randint(0, 4096, (planted,), generator=g, device=dev)] + 0.1 * torch.randn((planted, DIM), generator=g, device=dev) / DIM ** 0.5
+    q = torch.nn.functional.normalize(q, dim=1)
+    mean_cos = float((first[:1024] @ first[1024:2048].T).mean())
+    ms, kernel_ms, status, s1, i1 = _time_search(index, q, K, steps, ev, lib, n, 0, True)
+    ms_x, _, _, s2, i2 = _time_search(index, q, K, 2, ev, lib, n, 0, False)
+    same = bool(torch.equal(i1, i2) and torch.equal(s1, s2))
+    return {
+        "value": round(nq / ms * 1e3, 1), "unit": "queries/s", "ms_per_step": round(ms, 4),
+        "workload": f"{nq} queries x {n} rows: common component (mean pairwise cosine {mean_cos:.2f}), 64 clusters, 1 % near-duplicate "
+                    f"rows, 20 % of the queries planted next to corpus rows; screened search (mean-centred bf16 copy)",
+        "exact_fallback_queries": int(status[1]),
+        "screen_kernel_ms": round(kernel_ms, 4),
+        "equals_exact_scan_all_rows": same,
+        "exact_scan_queries_per_s": round(nq / ms_x * 1e3, 1),
+    }
+
+
+def bench_search_cfg3(pkg, lib, dev, nq, ev, n_total: int = 8_841_823, steps: int = 3):
+    """BASELINE cfg 3 sizes on ONE GPU: (a) the 1 105 228-row shard a rank of the 8-GPU job owns, screened (what the
+    N = 8 step costs per rank before the all-gather); (b) the whole 8 841 823-row corpus, exact fp32 scan - the
+    north star's "cosine top-k over 8.8M x 384-d" against the HBM roofline on SURVEY.md section 8(d)'s
+    algorithmic bytes - and screened."""
+    from semantic_search_kd_amd.dist import shard_bounds
+
+    g = torch.Generator(device=dev).manual_seed(1234)
+    index = pkg.FAISSIndexBuilder(embedding_dim=DIM, index_type="HNSW", metric="ip", device=str(dev))
+    index.reserve(n_total)
+    for lo in range(0, n_total, 1 << 20):
+        rows = torch.randn((min(1 << 20, n_total - lo), DIM), generator=g, device=dev)
+        index.add(torch.nn.functional.normalize(rows, dim=1))
+    del rows
+    q = torch.nn.functional.normalize(torch.randn((nq, DIM), generator=g, device=dev), dim=1)
+    out = {}
+    ms, kms, st, s1, i1 = _time_search(index, q, K, steps, ev, lib, n_total, 0, True)
+    out["whole_screened"] = {"value": round(nq / ms * 1e3, 1), "unit": "queries/s", "ms_per_step": round(ms, 3), "rows": n_total,
+                             "screen_kernel_ms": round(kms, 3), "exact_fallback_queries": int(st[1]),
+                             "mfma_bf16_frac": round(2.0 * nq * n_total * DIM / (kms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4)}
+    ms, kms, _, s2, i2 = _time_search(index, q, K, 2, ev, lib, n_total, 0, False)
+    qpb, passes, slices, waves, scans = (C.c_int() for _ in range(5))
+    lib.sskd_index_search_plan(n_total, nq, K, qpb, passes, slices, waves, scans)
+    alg = passes.value * n_total * DIM * 4 + nq * DIM * 4 + nq * K * 12
+    out["whole_exact"] = {"value": round(nq / ms * 1e3, 1), "unit": "queries/s", "ms_per_step": round(ms, 3), "rows": n_total,
+                          "scan_kernel_ms": round(kms, 3), "queries_per_block": qpb.value, "corpus_passes": passes.value,
+                          "mfma_f32_frac": round(2.0 * nq * n_total * DIM / (kms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
+                          "hbm_algorithmic_bytes": alg,
+                          "hbm_algorithmic_frac": round(alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          "equals_screened_all_rows": bool(torch.equal(i1, i2) and torch.equal(s1, s2))}
+    del index, s1, i1, s2, i2
+    torch.cuda.empty_cache()
+    lo, hi = shard_bounds(n_total, 8, 0)
+    g = torch.Generator(device=dev).manual_seed(1234)
+    shard = pkg.FAISSIndexBuilder(embedding_dim=DIM, index_type="HNSW", metric="ip", device=str(dev), id_offset=lo)
+    shard.add(torch.nn.functional.normalize(torch.randn((hi - lo, DIM), generator=g, device=dev), dim=1))
+    ms, kms, st, _, _ = _time_search(shard, q, K, 5, ev, lib, hi - lo, lo, True)
+    out["shard_of_8_screened"] = {"value": round(nq / ms * 1e3, 1), "unit": "queries/s", "ms_per_step": round(ms, 3), "rows": hi - lo,
+                                  "screen_kernel_ms": round(kms, 3), "exact_fallback_queries": int(st[1]),
+                                  "projected_speedup_at_8_gpus": round(out["whole_screened"]["ms_per_step"] / ms, 2)}
+    return out
 
 
 def self_launch(args) -> int:
@@ -194,7 +410,13 @@ def main() -> None:
     ap.add_argument("--no-teacher", action="store_true", help="skip the teacher cross-encoder leg (BASELINE cfg 5 model)")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous + one all-gather over gloo on CPU, no GPU work: tests the N > 1 launch plumbing")
+    ap.add_argument("--no-hostile", action="store_true", help="skip the anisotropic / near-duplicate search leg")
+    ap.add_argument("--no-cfg3", action="store_true", help="skip the BASELINE cfg-3 legs (8 841 823 rows: one shard + whole corpus)")
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_child:
+        cpu_baselines_child()
+        return
 
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(self_launch(args))  # nothing above this line touches the GPU
@@ -216,6 +438,9 @@ def main() -> None:
         if rank == 0:
             print(json.dumps({"launch_check": True, "ranks": world}), flush=True)
         return
+    # CPU baselines FIRST, in a child that never touches the GPU (rank 0 at N = 1 only); nothing above this line has
+    # initialised the GPU in this process either
+    cpu_lines = run_cpu_baselines_first(args) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -324,6 +549,21 @@ def main() -> None:
     ms_per_step = dt / args.steps * 1e3
     qps = nq * args.steps / dt
 
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # parity spot check of what was just measured: first 100 queries against the reference idiom
+        # (numpy sgemm + argsort) on the host, same vectors
+        from oracle import search as oracle
+
+        corpus_host, queries_host = shard.cpu().numpy(), queries[:100].cpu().numpy()
+        ref_s, ref_i = oracle.topk_blas(queries_host, corpus_host, K)
+        del corpus_host
+        got_s, got_i = res[0][:100].cpu().numpy(), res[1][:100].cpu().numpy()
+        ties = set(oracle.near_tie_queries(ref_s).tolist())
+        ok = all(np.array_equal(got_i[j], ref_i[j]) for j in range(100) if j not in ties)
+        parity = {"checked_queries": 100, "ids_identical": bool(ok),
+                  "max_abs_score_diff": float(np.abs(got_s - ref_s).max()), "near_tie_queries": len(ties)}
+
     scan_ms = float(np.mean([ev.elapsed_ms(a, b) for a, b in ev_pairs]))
     flops = 2.0 * nq * n_local * DIM
     traffic, traffic_from = None, None
@@ -345,15 +585,19 @@ def main() -> None:
         kernel_name, peak_tf = "scan_topk_kernel", MFMA_F32_PEAK_TF
         tpath = REPO / "profiles" / "scan_traffic.json"
     achieved_gbs = alg_bytes / (scan_ms * 1e-3) / 1e9
-    # HBM bytes per launch from the PMC counters: they cannot be read from inside this process, so the
-    # number comes from the committed rocprofv3 --pmc passes of this same command and says so
+    # HBM bytes per launch from the PMC counters: they cannot be read from inside this process, so the number comes
+    # from the committed rocprofv3 --pmc passes of this same command - and only while search.hip is byte-identical to
+    # the file those passes ran (sha recorded beside the number); otherwise traffic is null and says why
+    traffic_note = None
     if tpath.exists() and world == 1 and n == N_CORPUS and nq == N_QUERIES:
         try:
             tj = json.loads(tpath.read_text())
-            traffic, traffic_from = tj.get("hbm_bytes_per_launch"), tj.get("from")
+            if tj.get("search_hip_sha") == search_hip_sha():
+                traffic, traffic_from = tj.get("hbm_bytes_per_launch"), tj.get("from")
+            else:
+                traffic_note = f"stale: counters were collected at search.hip {tj.get('search_hip_sha')}, this is {search_hip_sha()}"
         except Exception:
             traffic = None
-
     line = {
         "metric": METRIC,
         "value": round(qps, 1),
@@ -381,10 +625,10 @@ def main() -> None:
             else "exact fp32 scan",
             "exact_fallback_queries": int(status[1].item()) if use_screen else 0,
         },
-        # The scan is bound by the fp32 matrix pipe, not by HBM: with B_q = 64 queries per block its
-        # MFMAs saturate at 4.9 TB/s of *algorithmic* corpus traffic, and the XCD-affine slice mapping
-        # serves most re-reads from L2 (see "traffic").  Both views are reported; "hbm_*" uses the
-        # B_q-dependent algorithmic bytes of SURVEY.md §8(d) against the 8 TB/s HBM peak.
+        # roofline of the dominant kernel.  Screened: bf16 MFMA peak (the B_q-dependent "algorithmic HBM bytes" of
+        # SURVEY.md section 8(d) are NOT reported for it - with 128 queries per workgroup they exceed what HBM can move,
+        # the slices of an XCD share tiles through L2; the counter traffic is the honest HBM figure).  Exact scan:
+        # fp32 MFMA peak, plus the section 8(d) algorithmic bytes against the 8 TB/s HBM peak.
         "roofline": {
             "bound": "mfma",
             "kernel": kernel_name,
@@ -394,14 +638,27 @@ def main() -> None:
             "frac": round(flops / (scan_ms * 1e-3) / 1e12 / peak_tf, 4),
             "traffic": traffic,
             "traffic_from": traffic_from,
+            "traffic_note": traffic_note,
+            "hbm_counter_gbs": round(traffic / (scan_ms * 1e-3) / 1e9, 1) if traffic else None,
             "kernel_ms": round(scan_ms, 4),
             "algorithmic_flops": flops,
+        },
+    }
+    if not use_screen:
+        line["roofline"].update({
             "hbm_algorithmic_bytes": alg_bytes,
             "hbm_algorithmic_gbs": round(achieved_gbs, 1),
             "hbm_algorithmic_frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
             "hbm_peak_gbs": HBM_PEAK_GBS,
-        },
-    }
+        })
+
+    # ---- hostile-data leg and the cfg-3 sizes (rank 0, N = 1) -----------------------------------------------------
+    if rank == 0 and world == 1 and not args.no_hostile and n >= 100_000:
+        line["search_anisotropic"] = bench_search_anisotropic(pkg, lib, dev, n, nq, ev)
+    if rank == 0 and world == 1 and not args.no_cfg3:
+        del index, shard
+        torch.cuda.empty_cache()
+        line["search_cfg3"] = bench_search_cfg3(pkg, lib, dev, nq, ev)
 
     # ---- encoder leg (docs embedded / s), once the kernels exist ---------------------------
     if not args.no_encode:
@@ -423,46 +680,17 @@ def main() -> None:
 
         line["kd_step"] = bench_kd_step(dev)
 
-    # ---- CPU baselines: rank 0, N = 1 only, AFTER every GPU leg (their BLAS / OpenMP worker threads keep
-    # spinning for a while and slow the launch thread of whatever GPU leg follows: the KD step read 41 ms
-    # instead of 35 ms when the encoder's CPU baseline ran before it) ---------------------------------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and "encode" in line:
-        line["encode"]["cpu_baseline"] = cpu_encode_baseline()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        corpus_host = shard.cpu().numpy()
-        queries_host = queries.cpu().numpy()
-        cpu_qps, cpu_nq, cpu_dt = cpu_search_baseline(corpus_host, queries_host, K)
-        threads = torch.get_num_threads()
-        try:
-            from threadpoolctl import threadpool_info
-
-            blas = [p["num_threads"] for p in threadpool_info() if p.get("user_api") == "blas"]
-            threads = max(blas) if blas else threads
-        except Exception:
-            pass
-        line["cpu_baseline"] = {
-            "value": round(cpu_qps, 2),
-            "unit": "queries/s",
-            "cores": threads,
-            "kind": "port",
-            "sample": f"{cpu_nq} of the {nq} queries against the full {n}-row corpus "
-            f"(numpy sgemm + argpartition, the reference's exact-search idiom), {cpu_dt:.1f} s",
-            "host_cpus": os.cpu_count(),
-            "faiss_hnsw": faiss_probe(),
-        }
-        # parity spot check of what was just measured (first 100 queries, vs the same idiom)
-        from oracle import search as oracle
-
-        ref_s, ref_i = oracle.topk_blas(queries_host[:100], corpus_host, K)
-        got_s, got_i = res[0][:100].cpu().numpy(), res[1][:100].cpu().numpy()
-        ties = set(oracle.near_tie_queries(ref_s).tolist())
-        ok = all(np.array_equal(got_i[j], ref_i[j]) for j in range(100) if j not in ties)
-        line["parity"] = {
-            "checked_queries": 100,
-            "ids_identical": bool(ok),
-            "max_abs_score_diff": float(np.abs(got_s - ref_s).max()),
-            "near_tie_queries": len(ties),
-        }
+    # ---- CPU baselines (measured first, in the child: see run_cpu_baselines_first) + parity spot check ----------
+    if cpu_lines is not None:
+        if "search" in cpu_lines:
+            line["cpu_baseline"] = cpu_lines["search"]
+        if "encode" in cpu_lines and "encode" in line:
+            line["encode"]["cpu_baseline"] = cpu_lines["encode"]
+        if "error" in cpu_lines:
+            line["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": physical_cores(), "kind": "port",
+                                    "sample": "child process failed: " + cpu_lines["error"]}
+    if parity is not None:
+        line["parity"] = parity
 
     if rank == 0:
         print(json.dumps(line), flush=True)

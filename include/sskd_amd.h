@@ -132,15 +132,18 @@ int sskd_index_search_profiled(const float* d_tiled, int64_t n_rows,
  * 1e-4 |q| max|row| (Cauchy-Schwarz on the two bf16 roundings + fp32 accumulation slack), with the
  * query norms taken per query and the row maxima when the sidecar is made; in the worst case (every
  * element on a bf16 tie) that is 2^-7 (1 + 2^-9) |q| max|row|, on random data about 0.42 of it.
+ * The bf16 copy holds the rows MINUS their mean row (q.mean is the same for every row of a query, so
+ * ranking is untouched): on anisotropic embeddings (e5: mean pairwise cosine 0.7-0.8) the centred norms,
+ * and with them the band, are 2-2.2x smaller.
  * Queries whose candidate band cannot be proven complete (a per-lane list full inside the band:
  * duplicate-heavy neighbourhoods) are answered by the exact scan inside the same call - the in-call
  * fallback is sized for every query, so no output row is ever unproven and callers have nothing to
  * check.  d_status (device int[2]): [0] = always 0 (kept for ABI stability), [1] = the number of
  * queries that took the exact fallback (a cost diagnostic).  d_bf16: the screening sidecar,
  * sskd_index_bf16_bytes(n_rows) bytes filled by sskd_index_make_bf16 from the CURRENT tiled index
- * (re-make it after sskd_index_add_rows): the bf16 tiles (768 B per row), a 256-byte block with
- * max |row|^2, max |row~|^2 and max |row~ - row|^2, and the fp32 rows row-major (1536 B per row: the
- * re-scoring gathers read whole cache lines from it). */
+ * (re-make it after sskd_index_add_rows): the bf16 tiles of the centred rows (768 B per row), a 4-KiB
+ * block with max |row|^2, max |row~|^2, max |row~ - (row - mean)|^2 and the column sums, and the ORIGINAL
+ * fp32 rows row-major (1536 B per row: the re-scoring gathers read whole cache lines from it). */
 size_t sskd_index_bf16_bytes(int64_t n_rows);
 int sskd_index_make_bf16(const float* d_tiled, int64_t n_rows, void* d_bf16, void* stream);
 size_t sskd_index_search_screened_workspace_bytes(int64_t n_rows, int nq, int k);

@@ -731,6 +731,14 @@ __global__ __launch_bounds__(64) void similarity_kernel(const float* __restrict_
 // (every element on a bf16 tie: relative rounding error 2^-8 per element, bf16 has 8 significand bits) this
 // is e = 2^-7 (1 + 2^-9) |q| |c|; random data rounds to about 0.42 of that.  Nothing about the rounding
 // mode is assumed - whatever the conversion did is what gets measured.
+// MEAN-CENTRING.  The screening copy holds bf16(c - mu), mu = the mean row of the shard: q.(c - mu) = q.c - q.mu and
+// q.mu is the same for every row of a query, so ranking, candidate band and k-th-best logic are untouched (they
+// only ever compare scores of ONE query), while every norm in the bound above becomes that of the CENTRED rows.
+// Real sentence embeddings are far from isotropic (e5: mean pairwise cosine 0.7-0.8): centring shrinks |c~| and
+// with it the band by 1 / sqrt(1 - cos) = 2-2.2x, which is the difference between ~40 and several hundred
+// candidates per query.  Any mu keeps the proof valid (it is a heuristic shift, computed once per make_bf16);
+// fl(c - mu) differs from c - mu by <= 2^-23 (|c| + |mu|) per row, inside SCREEN_ACC_SLACK.  Exact re-scoring
+// reads the ORIGINAL fp32 rows, so output bits are those of the exact scan.
 // With e bounding |screen score - exact fp32 score|, every row of the
 // exact top k has a screen score >= (k-th best screen score) - 2e: those rows are the candidates.
 // They are re-scored with the exact k-ordered fma chain of the fp32 MFMA, so the final scores and
@@ -774,12 +782,52 @@ constexpr int SCREEN_CUS = 256;                  // MI355X: the launch geometry 
 // Also writes the tile's 32 rows ROW-MAJOR in fp32 (rows_rm): the finalize kernel re-scores ~20 scattered
 // rows per query, and in the tiled layout a row is spread over 96 cache lines (16 useful bytes per 128-byte
 // line: 2.6 GB fetched for 0.3 GB used at the bench shape); row-major it is 12 whole lines.
-__global__ __launch_bounds__(256) void make_bf16_tiles_kernel(const float4* __restrict__ tiled, int64_t n_tiles,
-                                                              sbf16x8* __restrict__ out, int* __restrict__ max_norm2,
+// column sums of the tiled fp32 index -> colsum[384] (pre-zeroed): block b walks tiles b, b + grid, ...; thread
+// tid owns float4 slots tid + 256 i of every tile (fixed lane, steps (tid >> 6) + 4 i), reduces over the 32 rows of
+// its half-wave and adds once per block.  Rows past n_rows are zero in the tiled layout.
+__global__ __launch_bounds__(256) void tile_colsum_kernel(const float4* __restrict__ tiled, int64_t n_tiles,
+                                                          float* __restrict__ colsum) {
+  float4 acc[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const float4* src = tiled + t * (int64_t)(TILE_ROWS * CHUNKS) + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const float4 v = src[256 * i];
+      acc[i].x += v.x; acc[i].y += v.y; acc[i].z += v.z; acc[i].w += v.w;
+    }
+  }
+  const int l = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {   // within a 32-lane half: same columns, different rows
+      acc[i].x += __shfl_xor(acc[i].x, o); acc[i].y += __shfl_xor(acc[i].y, o);
+      acc[i].z += __shfl_xor(acc[i].z, o); acc[i].w += __shfl_xor(acc[i].w, o);
+    }
+    if ((l & 31) == 0) {
+      const int u = (threadIdx.x >> 6) + 4 * i;            // step: columns 8 u + 4 (l >> 5) + 0..3
+      float* dst = colsum + 8 * u + 4 * (l >> 5);
+      atomicAdd(dst + 0, acc[i].x); atomicAdd(dst + 1, acc[i].y); atomicAdd(dst + 2, acc[i].z); atomicAdd(dst + 3, acc[i].w);
+    }
+  }
+}
+
+// norm block of the sidecar: ints [0..2] = max |c|^2, max |c~|^2, max |c~ - fl(c - mu)|^2 (bit patterns of
+// non-negative floats), floats [64 .. 64 + 384) = column sums, then the mean row
+constexpr int SIDECAR_NORM_BYTES = 4096;
+constexpr int SIDECAR_COLSUM_OFF = 64;   // in floats
+
+__global__ __launch_bounds__(256) void make_bf16_tiles_kernel(const float4* __restrict__ tiled, int64_t n_tiles, int64_t n_rows,
+                                                              sbf16x8* __restrict__ out, int* __restrict__ norm_block,
                                                               float4* __restrict__ rows_rm) {
-  __shared__ float rowss[3][32];   // per row: |c|^2, |c~|^2, |c~ - c|^2
+  __shared__ float rowss[3][32];   // per row: |c|^2, |c~|^2, |c~ - fl(c - mu)|^2
+  __shared__ float mu[DIM];
   const int64_t t = blockIdx.x;
   if (threadIdx.x < 96) rowss[threadIdx.x >> 5][threadIdx.x & 31] = 0.f;
+  const float inv_n = 1.0f / (float)n_rows;
+  for (int c = threadIdx.x; c < DIM; c += 256) mu[c] = reinterpret_cast<const float*>(norm_block)[SIDECAR_COLSUM_OFF + c] * inv_n;
   __syncthreads();
   const float4* src = tiled + t * (int64_t)(TILE_ROWS * CHUNKS);
   for (int v = threadIdx.x; v < BTILE_VEC; v += 256) {
@@ -787,13 +835,15 @@ __global__ __launch_bounds__(256) void make_bf16_tiles_kernel(const float4* __re
     const int u = 2 * sidx + hh;
     const float4 a = src[u * 64 + r], b = src[u * 64 + r + 32];
     const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const bool live = t * TILE_ROWS + r < n_rows;   // padding rows stay all-zero (the kernel masks them anyway)
     sbf16x8 o;
     float nn = 0.f, bb = 0.f, dd = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      o[e] = (__bf16)x[e];
+      const float xc = live ? x[e] - mu[8 * u + e] : 0.f;   // fl(c - mu)
+      o[e] = (__bf16)xc;
       const float xr = (float)o[e];
-      const float d = xr - x[e];     // exact in fp32: xr is x[e] rounded to fewer bits
+      const float d = xr - xc;       // exact in fp32: xr is xc rounded to fewer bits
       nn = fmaf(x[e], x[e], nn);
       bb = fmaf(xr, xr, bb);
       dd = fmaf(d, d, dd);
@@ -808,7 +858,7 @@ __global__ __launch_bounds__(256) void make_bf16_tiles_kernel(const float4* __re
   }
   __syncthreads();
   // non-negative floats order as ints; words 0..2 of the sidecar's norm block
-  if (threadIdx.x < 96) atomicMax(max_norm2 + (threadIdx.x >> 5), __float_as_int(rowss[threadIdx.x >> 5][threadIdx.x & 31]));
+  if (threadIdx.x < 96) atomicMax(norm_block + (threadIdx.x >> 5), __float_as_int(rowss[threadIdx.x >> 5][threadIdx.x & 31]));
 }
 
 // per query: 2e = 2 (|q~ - q| max|c~| + |q| max|c~ - c| + SCREEN_ACC_SLACK |q| max|c|), rounded UP
@@ -1053,6 +1103,219 @@ __global__ __launch_bounds__(WAVES * 64) void screen_topk_kernel(ScreenParams p)
         p.part_scores[base + i] = list[qq].s[i];
         p.part_ids[base + i] = list[qq].id[i];
       }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------- //
+// Ring form of the screening pass (batch shapes with >= 512 queries).
+//
+// Ablations of screen_topk_kernel at the bench shape (tools/ab_search.py, gpurun_out/r03_abl1.log): 8.23 ms whole;
+// 6.49 ms without the corpus tile loads, 6.54 ms without the list maintenance, 8.59 ms without the LDS query reads,
+// 4.90 ms without loads AND LDS reads, 4.41 ms with nothing but the MFMAs (= the bare-loop rate).  The tile loads
+// are latency the two waves of a SIMD cannot hide: each wave streams its OWN tiles through 48 registers, two
+// 4-step groups ahead, and the register file has no room for more.
+//
+// Here the roles are swapped.  A wave keeps ITS 32 queries in registers for the whole kernel (24 B-operand
+// fragments = 96 VGPRs) and ALL 8 waves of a workgroup consume the SAME corpus tile, which arrives by LDS-DMA
+// (global_load_lds, no staging registers) in a ring of RING 24-KiB slots: RING - 2 tiles (3 us of matrix work) are
+// in flight ahead of the one being multiplied.  A workgroup therefore covers 256 queries (half the corpus passes of
+// the 128-query form: 40 instead of 79 at 10 k queries), a tile's 24 DMA pieces are 3 per wave, and per tile a wave
+// issues 24 MFMAs, each with one 1-KiB A fragment read from LDS (lane-linear image = the HBM tile layout:
+// conflict-free) against a register-resident B fragment.
+// Synchronisation, per tile i (slot i % RING): every wave waits for ITS pieces of tile i with a COUNTED vmcnt (the
+// pieces of the RING - 2 younger tiles stay in flight), one raw s_barrier makes all pieces visible to all waves and
+// proves that everybody is done reading tile i - 1, whose slot is then refilled with tile i + RING - 1.
+// A query's rows reach ONE wave per workgroup (two lanes: the row halves h = 0, 1), so the pruning bound needs no
+// LDS pool: each lane's list is LK >= K deep, its own K-th entry is a valid lower bound on the query's final K-th
+// screen score, the partner lane's comes by one cross-lane move, other slices' through tau / the global buckets at
+// a few exchange points (rare on purpose: a returning load drains the DMA pipeline once).
+// ------------------------------------------------------------------------- //
+constexpr int RING_WAVES = 8;
+constexpr int RING_SLOTS = 5;
+constexpr int RING_LISTK = 16;
+constexpr int RING_SLOT_BYTES = BTILE_VEC * 16;   // 24 KiB
+
+__device__ inline void ring_glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <int K, int LK>
+__global__ __launch_bounds__(RING_WAVES * 64) void screen_ring_kernel(ScreenParams p) {
+  static_assert(LK >= K, "a lane's own K-th entry must exist");
+  extern __shared__ __attribute__((aligned(16))) unsigned char ring_lds[];   // RING_SLOTS x 24 KiB, nothing else
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int n_qblocks = gridDim.x / p.n_slices;
+  const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+  const int logical = xcd * (gridDim.x >> 3) + min(xcd, (int)(gridDim.x & 7)) + within;   // see screen_topk_kernel
+  const int slice = logical / n_qblocks;
+  const int qblk = logical % n_qblocks;
+  const int qg = qblk * (32 * RING_WAVES) + 32 * wave + j;
+  const bool real = qg < p.nq;
+
+  // this lane's query as 24 B-operand fragments: elements 16 s + 8 h + 0..7, rounded to bf16 exactly as
+  // screen_eps_kernel measures it
+  sbf16x8 qf[BSTEPS];
+#pragma unroll
+  for (int sidx = 0; sidx < BSTEPS; ++sidx) {
+    sbf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+    if (real) {
+      const float4* src = reinterpret_cast<const float4*>(p.queries + (int64_t)qg * DIM + 16 * sidx + 8 * h);
+      const float4 a = src[0], b = src[1];
+      v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
+      v[4] = (__bf16)b.x; v[5] = (__bf16)b.y; v[6] = (__bf16)b.z; v[7] = (__bf16)b.w;
+    }
+    qf[sidx] = v;
+  }
+  const int qsafe = real ? qg : p.nq - 1;
+  float band = p.eps2[qsafe];
+  int* const tau_q = p.tau + qsafe;
+  int* const gb = p.gpool + (int64_t)qsafe * K;
+  LaneList<LK> list;
+  list.clear();
+  float gthr = -INFINITY;   // (best known lower bound on the query's final K-th SCREEN score) - 2e
+
+  const int t_begin = slice * p.tiles_per_slice;
+  const int n = min(t_begin + p.tiles_per_slice, p.n_tiles) - t_begin;
+  const bool ragged = (p.n_rows & 31) != 0;
+  const sbf16x8* const gsrc = p.tiled + (int64_t)t_begin * BTILE_VEC + wave * 64 + lane;   // piece `wave` of tile 0
+  auto issue = [&](int i, int slot) {   // this wave's 3 of the 24 pieces of tile t_begin + i
+    const sbf16x8* g = gsrc + (int64_t)i * BTILE_VEC;
+    unsigned char* l = ring_lds + slot * RING_SLOT_BYTES + wave * 1024;
+#pragma unroll
+    for (int pp = 0; pp < BSTEPS / RING_WAVES; ++pp) ring_glds16(g + pp * RING_WAVES * 64, l + pp * RING_WAVES * 1024);
+  };
+  // the waits below count exactly this wave's DMA pieces (+ the odd no-return atomic, which only makes them stricter).
+  // Everything loaded from global memory so far is CONSUMED here: otherwise hipcc places the wait for `band` at its
+  // first use inside the tile loop - a vmcnt(0) per tile that drains the DMA ring.
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(band) : : "memory");
+  for (int i = 0; i < RING_SLOTS - 1 && i < n; ++i) issue(i, i);
+
+  int slot = 0;
+  for (int i = 0; i < n; ++i) {
+    if (i + RING_SLOTS - 2 < n) __builtin_amdgcn_s_waitcnt(0x0F70 | (3 * (RING_SLOTS - 2)));   // vmcnt(9): tile i landed
+    else __builtin_amdgcn_s_waitcnt(0x0F70);                                                  // tail: drain
+    __builtin_amdgcn_s_barrier();
+    {
+      const int fill = slot == 0 ? RING_SLOTS - 1 : slot - 1;   // slot of tile i - 1 (or the spare one at i = 0)
+      if (i + RING_SLOTS - 1 < n) issue(i + RING_SLOTS - 1, fill);
+    }
+    // bounds: own list and the partner half's every tile, the other slices' at a few points
+    {
+      const float own = list.s[K - 1];
+      // partner half's bound: v_permlane32_swap (VALU; a ds_bpermute would sit in the LDS queue behind the fragment reads)
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(own), __float_as_uint(own), false, false);
+      const float both = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));   // max(own, other half's), in every lane
+      gthr = fmaxf(gthr, both - band);
+      const bool exchange = i > 0 && ((i & (i - 1)) == 0 || (i & 1023) == 0);   // tiles 1, 2, 4, ..., 1024, then every 1024
+      if (exchange) {
+        int bmin = __hip_atomic_load(&gb[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int b = 1; b < K; ++b) bmin = min(bmin, __hip_atomic_load(&gb[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const int mine = float_to_ordered(both);
+        int seen = bmin;
+        if (real) seen = max(seen, atomicMax(tau_q, max(mine, bmin)));
+        gthr = fmaxf(gthr, ordered_to_float(seen) - band);
+      }
+    }
+    const sbf16x8* const a = reinterpret_cast<const sbf16x8*>(ring_lds + slot * RING_SLOT_BYTES) + lane;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // fragment reads RING_DEPTH ahead of their MFMA (left alone, hipcc reads each fragment into one register set
+    // right before its MFMA: one LDS latency per MFMA); the order is pinned, the counted lgkmcnt waits are hipcc's
+    constexpr int RING_DEPTH = 6;
+    sbf16x8 f[RING_DEPTH];
+#ifndef SSKD_RING_COMPILER_WAITS
+    // The reads are asm statements hipcc does not count (it waits lgkmcnt(0) for its own, i.e. for the YOUNGEST read
+    // in flight, every time); the waits are ours: LDS reads return in order, so lgkmcnt(RING_DEPTH - 1) before the MFMA
+    // of fragment s retires exactly that fragment.  No other LDS operation exists between the first read and the
+    // last wait of this block, sched_barrier pins the order (cdna_hip_programming.md section 5.7, form (iii)).
+    const unsigned lds_a = (unsigned)(uintptr_t)a;   // LDS byte address of this lane's slice of the slot
+#define RING_READ(dst, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_a), "i"(off))
+#define RING_WAIT(n)                                        \
+  do {                                                      \
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(n) : "memory"); \
+    __builtin_amdgcn_sched_barrier(0);                      \
+  } while (0)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int d = 0; d < RING_DEPTH; ++d) {
+      RING_READ(f[d], d * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int sidx = 0; sidx < BSTEPS; ++sidx) {
+      if (sidx + RING_DEPTH <= BSTEPS) RING_WAIT(RING_DEPTH - 1);
+      else RING_WAIT(BSTEPS - 1 - sidx);                     // tail: fewer reads behind this one
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[sidx % RING_DEPTH], qf[sidx], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (sidx + RING_DEPTH < BSTEPS) {
+        RING_READ(f[sidx % RING_DEPTH], (sidx + RING_DEPTH) * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#undef RING_READ
+#undef RING_WAIT
+#else
+#pragma unroll
+    for (int d = 0; d < RING_DEPTH; ++d) {
+      f[d] = a[d * 64];
+      __builtin_amdgcn_sched_barrier(0);   // program order IS the schedule here
+    }
+#pragma unroll
+    for (int sidx = 0; sidx < BSTEPS; ++sidx) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[sidx % RING_DEPTH], qf[sidx], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (sidx + RING_DEPTH < BSTEPS) {
+        f[sidx % RING_DEPTH] = a[(sidx + RING_DEPTH) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#endif
+
+    const int t = t_begin + i;
+    const int rowbase = t * TILE_ROWS + 4 * h;
+    if (ragged && t == p.n_tiles - 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (rowbase + (r & 3) + 8 * (r >> 2) >= p.n_rows) acc[r] = -INFINITY;
+    }
+    float m = acc[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+    if (__any(m > list.s[LK - 1] && m >= gthr)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float x = acc[r];
+        const int xid = rowbase + (r & 3) + 8 * (r >> 2);
+        const bool take = x > list.s[LK - 1] && x >= gthr;
+        if (__any(take)) {
+          if (take) {
+            // a row entering this lane's K best also feeds the query's global buckets (fire and forget)
+            if (real && x > list.s[K - 1])
+              (void)__hip_atomic_fetch_max(gb + xid % K, float_to_ordered(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            list.insert(x, xid);
+          }
+        }
+      }
+      gthr = fmaxf(gthr, list.s[K - 1] - band);
+    }
+    slot = slot + 1 == RING_SLOTS ? 0 : slot + 1;
+  }
+
+  if (real) {
+    const int64_t base = ((int64_t)qg * p.lists_per_query + slice * 2 + h) * LK;
+#pragma unroll
+    for (int e = 0; e < LK; ++e) {
+      p.part_scores[base + e] = list.s[e];
+      p.part_ids[base + e] = list.id[e];
     }
   }
 }
@@ -1769,12 +2032,44 @@ namespace {
 struct ScreenPlan {
   int QB, LK, n_qblocks, n_slices, tiles_per_slice, n_tiles, lists_per_query;
   size_t part_elems;
+  bool ring;   // screen_ring_kernel (256 queries per workgroup, tiles through the LDS-DMA ring)
 };
+
+#ifndef SSKD_SCREEN_RING_MIN_NQ
+#define SSKD_SCREEN_RING_MIN_NQ 512   // below two full query blocks the 128- / 64-query form wastes fewer MFMAs on padding
+#endif
 
 bool screen_plan(int64_t n_rows, int nq, int k, ScreenPlan* sp) {
   if (k < 1 || k > 10 || nq < 64 || n_rows < 64 * TILE_ROWS) return false;
   ScreenPlan pl{};
   pl.n_tiles = (int)sskd::ceil_div(n_rows, TILE_ROWS);
+  if (nq >= SSKD_SCREEN_RING_MIN_NQ) {
+    // ring form: one workgroup = 256 queries x one slice of tiles; whole rounds of the chip's 256 CUs (one
+    // workgroup per CU: 120 KiB of LDS), at least 64 tiles per slice so that the ring's start-up is amortised
+    pl.ring = true;
+    pl.QB = 8;
+    pl.LK = RING_LISTK;
+    pl.n_qblocks = (int)sskd::ceil_div(nq, 32 * RING_WAVES);
+    const int max_slices = std::min(std::max(1, pl.n_tiles / 64), SCREEN_MAX_ENTRIES / (2 * RING_LISTK));
+    int slices = 1;
+    double best = 1e300;
+    for (int rounds = 1; rounds <= 8; ++rounds) {
+      const int sl = std::min(std::max(1, rounds * SCREEN_CUS / pl.n_qblocks), max_slices);
+      const int wgs = sl * pl.n_qblocks;
+      const double util = (double)wgs / ((double)SCREEN_CUS * sskd::ceil_div(wgs, SCREEN_CUS));
+      const double cost = 1.0 / util + 0.01 * sl;   // mild preference for fewer, longer slices (each warms up cold)
+      if (cost < best - 1e-9) { best = cost; slices = sl; }
+    }
+#ifdef SSKD_SCREEN_FORCE_SLICES
+    slices = SSKD_SCREEN_FORCE_SLICES;
+#endif
+    pl.tiles_per_slice = (int)sskd::ceil_div(pl.n_tiles, slices);
+    pl.n_slices = (int)sskd::ceil_div(pl.n_tiles, pl.tiles_per_slice);
+    pl.lists_per_query = pl.n_slices * 2;
+    pl.part_elems = (size_t)nq * pl.lists_per_query * pl.LK;
+    *sp = pl;
+    return true;
+  }
   // 128 queries per workgroup (QB = 4) halve the corpus re-reads per MFMA: at 64 queries the tile loads
   // from L2 take as long as the MFMAs they feed.  Measured on 125 k .. 1 M rows x 10 k queries
   // (tools/ab_search.py with the FORCE macros below): QB = 4 wins at every size.
@@ -1864,9 +2159,9 @@ ScreenWs screen_carve(void* base, const ScreenPlan& pl, int64_t n_rows, int nq, 
 }
 }  // namespace
 
-// screening sidecar: [bf16 tiles][256 B: max |row|^2][fp32 rows, row-major (re-scoring gathers)]
+// screening sidecar: [bf16 tiles of the CENTRED rows][4 KiB: norm maxima + column sums][fp32 rows, row-major (re-scoring gathers)]
 static inline size_t sidecar_norm_offset(int64_t n_rows) { return (size_t)sskd::ceil_div(n_rows, TILE_ROWS) * BTILE_VEC * 16; }
-static inline size_t sidecar_rows_offset(int64_t n_rows) { return sidecar_norm_offset(n_rows) + 256; }
+static inline size_t sidecar_rows_offset(int64_t n_rows) { return sidecar_norm_offset(n_rows) + SIDECAR_NORM_BYTES; }
 
 size_t sskd_index_bf16_bytes(int64_t n_rows) {
   if (n_rows <= 0) return 0;
@@ -1881,9 +2176,13 @@ int sskd_index_make_bf16(const float* d_tiled, int64_t n_rows, void* d_bf16, voi
   const int64_t tiles = sskd::ceil_div(n_rows, TILE_ROWS);
   int* max_norm2 = reinterpret_cast<int*>(static_cast<char*>(d_bf16) + sidecar_norm_offset(n_rows));
   float4* rows_rm = reinterpret_cast<float4*>(static_cast<char*>(d_bf16) + sidecar_rows_offset(n_rows));
-  if (hipMemsetAsync(max_norm2, 0, 256, st) != hipSuccess) return sskd::fail(SSKD_ERR_HIP, "index_make_bf16: memset failed");
+  if (hipMemsetAsync(max_norm2, 0, SIDECAR_NORM_BYTES, st) != hipSuccess) return sskd::fail(SSKD_ERR_HIP, "index_make_bf16: memset failed");
+  hipLaunchKernelGGL(tile_colsum_kernel, dim3((unsigned)(tiles < 1024 ? tiles : 1024)), dim3(256), 0, st,
+                     reinterpret_cast<const float4*>(d_tiled), tiles, reinterpret_cast<float*>(max_norm2) + SIDECAR_COLSUM_OFF);
+  int rc = sskd::check_launch("tile_colsum_kernel");
+  if (rc != SSKD_OK) return rc;
   hipLaunchKernelGGL(make_bf16_tiles_kernel, dim3((unsigned)tiles), dim3(256), 0, st,
-                     reinterpret_cast<const float4*>(d_tiled), tiles, static_cast<sbf16x8*>(d_bf16), max_norm2, rows_rm);
+                     reinterpret_cast<const float4*>(d_tiled), tiles, n_rows, static_cast<sbf16x8*>(d_bf16), max_norm2, rows_rm);
   return sskd::check_launch("make_bf16_tiles_kernel");
 }
 
@@ -1943,9 +2242,13 @@ int sskd_index_search_screened(const float* d_tiled, const void* d_bf16, int64_t
   sp.n_slices = pl.n_slices;
   sp.tiles_per_slice = pl.tiles_per_slice;
   sp.lists_per_query = pl.lists_per_query;
-  const size_t lds = (size_t)pl.QB * BSTEPS * 64 * 16 + (size_t)pl.QB * 32 * 11 * sizeof(int);
+  size_t lds = (size_t)pl.QB * BSTEPS * 64 * 16 + (size_t)pl.QB * 32 * 11 * sizeof(int);
   if (ev_scan_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_scan_begin), st);
   const void* kern = nullptr;
+  if (pl.ring) {
+    kern = reinterpret_cast<const void*>(screen_ring_kernel<10, RING_LISTK>);
+    lds = (size_t)RING_SLOTS * RING_SLOT_BYTES;
+  } else
 #ifdef SSKD_SCREEN_FORCE_LK
   if (pl.QB == 4) kern = reinterpret_cast<const void*>(screen_topk_kernel<10, 4, SCREEN_WAVES, SSKD_SCREEN_FORCE_LK>);
   else kern = reinterpret_cast<const void*>(screen_topk_kernel<10, 2, SCREEN_WAVES, SSKD_SCREEN_FORCE_LK>);
