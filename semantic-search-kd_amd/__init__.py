@@ -15,7 +15,7 @@ from .student import StudentModel  # noqa: F401
 from .losses import CombinedKDLoss, ContrastiveLoss, ListwiseKDLoss, MarginMSELoss  # noqa: F401
 from .mining import ANCEMiner, TeacherMiner  # noqa: F401
 from .teacher import TeacherConfig, TeacherModel  # noqa: F401
-from .bench_support import bench_encode, encoder_smoke_embeddings  # noqa: F401
+from .bench_support import bench_encode  # noqa: F401
 
 Mi355xIndexBuilder = FAISSIndexBuilder
 

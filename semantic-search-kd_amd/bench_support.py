@@ -280,16 +280,3 @@ def bench_teacher(device, world: int, steps: int, warmup: int, barrier, pairs: i
         "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                      "frac": round(tf / MFMA_BF16_PEAK_TF, 4), "algorithmic_flops_per_step": flops},
     }
-
-
-def encoder_smoke_embeddings(device: str = "cuda:0"):
-    """Tiny forward of a 2-layer synthetic encoder on the golden l2 input; returns (embeddings, ids, mask)
-    for the caller (``__graft_entry__.smoke``) to compare against the committed golden vectors."""
-    from pathlib import Path
-
-    golden = np.load(Path(__file__).resolve().parent.parent / "tests" / "golden" / "bert_l2.npz")
-    cfg = BertConfig(num_hidden_layers=int(golden["layers"]))
-    enc = Mi355xSentenceEncoder.from_synthetic(cfg, device=device)
-    emb = enc.encode_token_ids(golden["input_ids"], golden["attention_mask"], normalize=True)
-    torch.cuda.synchronize()
-    return emb.cpu().numpy(), golden["embeddings"]

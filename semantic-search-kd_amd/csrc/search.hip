@@ -1107,219 +1107,6 @@ __global__ __launch_bounds__(WAVES * 64) void screen_topk_kernel(ScreenParams p)
   }
 }
 
-// ------------------------------------------------------------------------- //
-// Ring form of the screening pass (batch shapes with >= 512 queries).
-//
-// Ablations of screen_topk_kernel at the bench shape (tools/ab_search.py, gpurun_out/r03_abl1.log): 8.23 ms whole;
-// 6.49 ms without the corpus tile loads, 6.54 ms without the list maintenance, 8.59 ms without the LDS query reads,
-// 4.90 ms without loads AND LDS reads, 4.41 ms with nothing but the MFMAs (= the bare-loop rate).  The tile loads
-// are latency the two waves of a SIMD cannot hide: each wave streams its OWN tiles through 48 registers, two
-// 4-step groups ahead, and the register file has no room for more.
-//
-// Here the roles are swapped.  A wave keeps ITS 32 queries in registers for the whole kernel (24 B-operand
-// fragments = 96 VGPRs) and ALL 8 waves of a workgroup consume the SAME corpus tile, which arrives by LDS-DMA
-// (global_load_lds, no staging registers) in a ring of RING 24-KiB slots: RING - 2 tiles (3 us of matrix work) are
-// in flight ahead of the one being multiplied.  A workgroup therefore covers 256 queries (half the corpus passes of
-// the 128-query form: 40 instead of 79 at 10 k queries), a tile's 24 DMA pieces are 3 per wave, and per tile a wave
-// issues 24 MFMAs, each with one 1-KiB A fragment read from LDS (lane-linear image = the HBM tile layout:
-// conflict-free) against a register-resident B fragment.
-// Synchronisation, per tile i (slot i % RING): every wave waits for ITS pieces of tile i with a COUNTED vmcnt (the
-// pieces of the RING - 2 younger tiles stay in flight), one raw s_barrier makes all pieces visible to all waves and
-// proves that everybody is done reading tile i - 1, whose slot is then refilled with tile i + RING - 1.
-// A query's rows reach ONE wave per workgroup (two lanes: the row halves h = 0, 1), so the pruning bound needs no
-// LDS pool: each lane's list is LK >= K deep, its own K-th entry is a valid lower bound on the query's final K-th
-// screen score, the partner lane's comes by one cross-lane move, other slices' through tau / the global buckets at
-// a few exchange points (rare on purpose: a returning load drains the DMA pipeline once).
-// ------------------------------------------------------------------------- //
-constexpr int RING_WAVES = 8;
-constexpr int RING_SLOTS = 5;
-constexpr int RING_LISTK = 16;
-constexpr int RING_SLOT_BYTES = BTILE_VEC * 16;   // 24 KiB
-
-__device__ inline void ring_glds16(const void* g, void* l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-}
-
-template <int K, int LK>
-__global__ __launch_bounds__(RING_WAVES * 64) void screen_ring_kernel(ScreenParams p) {
-  static_assert(LK >= K, "a lane's own K-th entry must exist");
-  extern __shared__ __attribute__((aligned(16))) unsigned char ring_lds[];   // RING_SLOTS x 24 KiB, nothing else
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 31, h = lane >> 5;
-  const int n_qblocks = gridDim.x / p.n_slices;
-  const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
-  const int logical = xcd * (gridDim.x >> 3) + min(xcd, (int)(gridDim.x & 7)) + within;   // see screen_topk_kernel
-  const int slice = logical / n_qblocks;
-  const int qblk = logical % n_qblocks;
-  const int qg = qblk * (32 * RING_WAVES) + 32 * wave + j;
-  const bool real = qg < p.nq;
-
-  // this lane's query as 24 B-operand fragments: elements 16 s + 8 h + 0..7, rounded to bf16 exactly as
-  // screen_eps_kernel measures it
-  sbf16x8 qf[BSTEPS];
-#pragma unroll
-  for (int sidx = 0; sidx < BSTEPS; ++sidx) {
-    sbf16x8 v;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
-    if (real) {
-      const float4* src = reinterpret_cast<const float4*>(p.queries + (int64_t)qg * DIM + 16 * sidx + 8 * h);
-      const float4 a = src[0], b = src[1];
-      v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
-      v[4] = (__bf16)b.x; v[5] = (__bf16)b.y; v[6] = (__bf16)b.z; v[7] = (__bf16)b.w;
-    }
-    qf[sidx] = v;
-  }
-  const int qsafe = real ? qg : p.nq - 1;
-  float band = p.eps2[qsafe];
-  int* const tau_q = p.tau + qsafe;
-  int* const gb = p.gpool + (int64_t)qsafe * K;
-  LaneList<LK> list;
-  list.clear();
-  float gthr = -INFINITY;   // (best known lower bound on the query's final K-th SCREEN score) - 2e
-
-  const int t_begin = slice * p.tiles_per_slice;
-  const int n = min(t_begin + p.tiles_per_slice, p.n_tiles) - t_begin;
-  const bool ragged = (p.n_rows & 31) != 0;
-  const sbf16x8* const gsrc = p.tiled + (int64_t)t_begin * BTILE_VEC + wave * 64 + lane;   // piece `wave` of tile 0
-  auto issue = [&](int i, int slot) {   // this wave's 3 of the 24 pieces of tile t_begin + i
-    const sbf16x8* g = gsrc + (int64_t)i * BTILE_VEC;
-    unsigned char* l = ring_lds + slot * RING_SLOT_BYTES + wave * 1024;
-#pragma unroll
-    for (int pp = 0; pp < BSTEPS / RING_WAVES; ++pp) ring_glds16(g + pp * RING_WAVES * 64, l + pp * RING_WAVES * 1024);
-  };
-  // the waits below count exactly this wave's DMA pieces (+ the odd no-return atomic, which only makes them stricter).
-  // Everything loaded from global memory so far is CONSUMED here: otherwise hipcc places the wait for `band` at its
-  // first use inside the tile loop - a vmcnt(0) per tile that drains the DMA ring.
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(band) : : "memory");
-  for (int i = 0; i < RING_SLOTS - 1 && i < n; ++i) issue(i, i);
-
-  int slot = 0;
-  for (int i = 0; i < n; ++i) {
-    if (i + RING_SLOTS - 2 < n) __builtin_amdgcn_s_waitcnt(0x0F70 | (3 * (RING_SLOTS - 2)));   // vmcnt(9): tile i landed
-    else __builtin_amdgcn_s_waitcnt(0x0F70);                                                  // tail: drain
-    __builtin_amdgcn_s_barrier();
-    {
-      const int fill = slot == 0 ? RING_SLOTS - 1 : slot - 1;   // slot of tile i - 1 (or the spare one at i = 0)
-      if (i + RING_SLOTS - 1 < n) issue(i + RING_SLOTS - 1, fill);
-    }
-    // bounds: own list and the partner half's every tile, the other slices' at a few points
-    {
-      const float own = list.s[K - 1];
-      // partner half's bound: v_permlane32_swap (VALU; a ds_bpermute would sit in the LDS queue behind the fragment reads)
-      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(own), __float_as_uint(own), false, false);
-      const float both = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));   // max(own, other half's), in every lane
-      gthr = fmaxf(gthr, both - band);
-      const bool exchange = i > 0 && ((i & (i - 1)) == 0 || (i & 1023) == 0);   // tiles 1, 2, 4, ..., 1024, then every 1024
-      if (exchange) {
-        int bmin = __hip_atomic_load(&gb[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int b = 1; b < K; ++b) bmin = min(bmin, __hip_atomic_load(&gb[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        const int mine = float_to_ordered(both);
-        int seen = bmin;
-        if (real) seen = max(seen, atomicMax(tau_q, max(mine, bmin)));
-        gthr = fmaxf(gthr, ordered_to_float(seen) - band);
-      }
-    }
-    const sbf16x8* const a = reinterpret_cast<const sbf16x8*>(ring_lds + slot * RING_SLOT_BYTES) + lane;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    // fragment reads RING_DEPTH ahead of their MFMA (left alone, hipcc reads each fragment into one register set
-    // right before its MFMA: one LDS latency per MFMA); the order is pinned, the counted lgkmcnt waits are hipcc's
-    constexpr int RING_DEPTH = 6;
-    sbf16x8 f[RING_DEPTH];
-#ifndef SSKD_RING_COMPILER_WAITS
-    // The reads are asm statements hipcc does not count (it waits lgkmcnt(0) for its own, i.e. for the YOUNGEST read
-    // in flight, every time); the waits are ours: LDS reads return in order, so lgkmcnt(RING_DEPTH - 1) before the MFMA
-    // of fragment s retires exactly that fragment.  No other LDS operation exists between the first read and the
-    // last wait of this block, sched_barrier pins the order (cdna_hip_programming.md section 5.7, form (iii)).
-    const unsigned lds_a = (unsigned)(uintptr_t)a;   // LDS byte address of this lane's slice of the slot
-#define RING_READ(dst, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_a), "i"(off))
-#define RING_WAIT(n)                                        \
-  do {                                                      \
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(n) : "memory"); \
-    __builtin_amdgcn_sched_barrier(0);                      \
-  } while (0)
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int d = 0; d < RING_DEPTH; ++d) {
-      RING_READ(f[d], d * 1024);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int sidx = 0; sidx < BSTEPS; ++sidx) {
-      if (sidx + RING_DEPTH <= BSTEPS) RING_WAIT(RING_DEPTH - 1);
-      else RING_WAIT(BSTEPS - 1 - sidx);                     // tail: fewer reads behind this one
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[sidx % RING_DEPTH], qf[sidx], acc, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (sidx + RING_DEPTH < BSTEPS) {
-        RING_READ(f[sidx % RING_DEPTH], (sidx + RING_DEPTH) * 1024);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-#undef RING_READ
-#undef RING_WAIT
-#else
-#pragma unroll
-    for (int d = 0; d < RING_DEPTH; ++d) {
-      f[d] = a[d * 64];
-      __builtin_amdgcn_sched_barrier(0);   // program order IS the schedule here
-    }
-#pragma unroll
-    for (int sidx = 0; sidx < BSTEPS; ++sidx) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[sidx % RING_DEPTH], qf[sidx], acc, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (sidx + RING_DEPTH < BSTEPS) {
-        f[sidx % RING_DEPTH] = a[(sidx + RING_DEPTH) * 64];
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-#endif
-
-    const int t = t_begin + i;
-    const int rowbase = t * TILE_ROWS + 4 * h;
-    if (ragged && t == p.n_tiles - 1) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (rowbase + (r & 3) + 8 * (r >> 2) >= p.n_rows) acc[r] = -INFINITY;
-    }
-    float m = acc[0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
-    if (__any(m > list.s[LK - 1] && m >= gthr)) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float x = acc[r];
-        const int xid = rowbase + (r & 3) + 8 * (r >> 2);
-        const bool take = x > list.s[LK - 1] && x >= gthr;
-        if (__any(take)) {
-          if (take) {
-            // a row entering this lane's K best also feeds the query's global buckets (fire and forget)
-            if (real && x > list.s[K - 1])
-              (void)__hip_atomic_fetch_max(gb + xid % K, float_to_ordered(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            list.insert(x, xid);
-          }
-        }
-      }
-      gthr = fmaxf(gthr, list.s[K - 1] - band);
-    }
-    slot = slot + 1 == RING_SLOTS ? 0 : slot + 1;
-  }
-
-  if (real) {
-    const int64_t base = ((int64_t)qg * p.lists_per_query + slice * 2 + h) * LK;
-#pragma unroll
-    for (int e = 0; e < LK; ++e) {
-      p.part_scores[base + e] = list.s[e];
-      p.part_ids[base + e] = list.id[e];
-    }
-  }
-}
-
 struct ScreenFinalParams {
   const float* part_scores;   // [nq][lists][K] screen scores (sorted lists, (-inf, -1) padded)
   const int* part_ids;
@@ -2032,44 +1819,12 @@ namespace {
 struct ScreenPlan {
   int QB, LK, n_qblocks, n_slices, tiles_per_slice, n_tiles, lists_per_query;
   size_t part_elems;
-  bool ring;   // screen_ring_kernel (256 queries per workgroup, tiles through the LDS-DMA ring)
 };
-
-#ifndef SSKD_SCREEN_RING_MIN_NQ
-#define SSKD_SCREEN_RING_MIN_NQ 512   // below two full query blocks the 128- / 64-query form wastes fewer MFMAs on padding
-#endif
 
 bool screen_plan(int64_t n_rows, int nq, int k, ScreenPlan* sp) {
   if (k < 1 || k > 10 || nq < 64 || n_rows < 64 * TILE_ROWS) return false;
   ScreenPlan pl{};
   pl.n_tiles = (int)sskd::ceil_div(n_rows, TILE_ROWS);
-  if (nq >= SSKD_SCREEN_RING_MIN_NQ) {
-    // ring form: one workgroup = 256 queries x one slice of tiles; whole rounds of the chip's 256 CUs (one
-    // workgroup per CU: 120 KiB of LDS), at least 64 tiles per slice so that the ring's start-up is amortised
-    pl.ring = true;
-    pl.QB = 8;
-    pl.LK = RING_LISTK;
-    pl.n_qblocks = (int)sskd::ceil_div(nq, 32 * RING_WAVES);
-    const int max_slices = std::min(std::max(1, pl.n_tiles / 64), SCREEN_MAX_ENTRIES / (2 * RING_LISTK));
-    int slices = 1;
-    double best = 1e300;
-    for (int rounds = 1; rounds <= 8; ++rounds) {
-      const int sl = std::min(std::max(1, rounds * SCREEN_CUS / pl.n_qblocks), max_slices);
-      const int wgs = sl * pl.n_qblocks;
-      const double util = (double)wgs / ((double)SCREEN_CUS * sskd::ceil_div(wgs, SCREEN_CUS));
-      const double cost = 1.0 / util + 0.01 * sl;   // mild preference for fewer, longer slices (each warms up cold)
-      if (cost < best - 1e-9) { best = cost; slices = sl; }
-    }
-#ifdef SSKD_SCREEN_FORCE_SLICES
-    slices = SSKD_SCREEN_FORCE_SLICES;
-#endif
-    pl.tiles_per_slice = (int)sskd::ceil_div(pl.n_tiles, slices);
-    pl.n_slices = (int)sskd::ceil_div(pl.n_tiles, pl.tiles_per_slice);
-    pl.lists_per_query = pl.n_slices * 2;
-    pl.part_elems = (size_t)nq * pl.lists_per_query * pl.LK;
-    *sp = pl;
-    return true;
-  }
   // 128 queries per workgroup (QB = 4) halve the corpus re-reads per MFMA: at 64 queries the tile loads
   // from L2 take as long as the MFMAs they feed.  Measured on 125 k .. 1 M rows x 10 k queries
   // (tools/ab_search.py with the FORCE macros below): QB = 4 wins at every size.
@@ -2242,13 +1997,9 @@ int sskd_index_search_screened(const float* d_tiled, const void* d_bf16, int64_t
   sp.n_slices = pl.n_slices;
   sp.tiles_per_slice = pl.tiles_per_slice;
   sp.lists_per_query = pl.lists_per_query;
-  size_t lds = (size_t)pl.QB * BSTEPS * 64 * 16 + (size_t)pl.QB * 32 * 11 * sizeof(int);
+  const size_t lds = (size_t)pl.QB * BSTEPS * 64 * 16 + (size_t)pl.QB * 32 * 11 * sizeof(int);
   if (ev_scan_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_scan_begin), st);
   const void* kern = nullptr;
-  if (pl.ring) {
-    kern = reinterpret_cast<const void*>(screen_ring_kernel<10, RING_LISTK>);
-    lds = (size_t)RING_SLOTS * RING_SLOT_BYTES;
-  } else
 #ifdef SSKD_SCREEN_FORCE_LK
   if (pl.QB == 4) kern = reinterpret_cast<const void*>(screen_topk_kernel<10, 4, SCREEN_WAVES, SSKD_SCREEN_FORCE_LK>);
   else kern = reinterpret_cast<const void*>(screen_topk_kernel<10, 2, SCREEN_WAVES, SSKD_SCREEN_FORCE_LK>);

@@ -207,8 +207,12 @@ class FAISSIndexBuilder:
         self.reserve(len(texts))
         # stream in slabs so a multi-million-passage corpus never needs one host matrix
         slab = max(batch_size, 65536)
+        on_device = getattr(model, "encode_documents_device", None)   # embeddings go encoder -> index tiles inside HBM
         for lo in range(0, len(texts), slab):
-            embs = model.encode_documents(texts[lo : lo + slab], batch_size=batch_size, show_progress=show_progress)
+            if on_device is not None:
+                embs = on_device(texts[lo : lo + slab], batch_size=batch_size)
+            else:
+                embs = model.encode_documents(texts[lo : lo + slab], batch_size=batch_size, show_progress=show_progress)
             self.add(embs)
         self.doc_ids = ids
         self.doc_texts = dict(zip(ids, texts))

@@ -106,12 +106,18 @@ class ANCEMiner:
         pos_idx = [[slot("p", d, positive_texts) for d in ids] for ids in positives]
         cand_idx = [[slot("c", d, candidate_texts) for d in ids] for ids in candidates]
         d_embs = np.asarray(self.student.encode_documents(texts)) if texts else np.zeros((0, q_embs.shape[1]), np.float32)
+        # ONE similarity launch per block of queries (every query x every distinct text; a (query, text) score does
+        # not depend on its batch-mates), not two launches + two host round trips per query as in the reference loop
         out: List[List[str]] = []
-        for qi, (p_ix, c_ix, c_ids) in enumerate(zip(pos_idx, cand_idx, candidates)):
-            q = q_embs[qi].reshape(1, -1)
-            pos_scores = self.student.compute_similarity(q, d_embs[p_ix])[0] if p_ix else np.zeros(0, np.float32)
-            cand_scores = self.student.compute_similarity(q, d_embs[c_ix])[0] if c_ix else np.zeros(0, np.float32)
-            out.append(select_adversarial(c_ids, cand_scores, pos_scores, self.margin, top_k))
+        block = max(1, (1 << 24) // max(len(texts), 1))
+        for q_lo in range(0, len(queries), block):
+            sims = (np.asarray(self.student.compute_similarity(q_embs[q_lo : q_lo + block], d_embs))
+                    if texts else np.zeros((len(q_embs[q_lo : q_lo + block]), 0), np.float32))
+            for qi in range(q_lo, min(q_lo + block, len(queries))):
+                row = sims[qi - q_lo]
+                pos_scores = row[pos_idx[qi]] if pos_idx[qi] else np.zeros(0, np.float32)
+                cand_scores = row[cand_idx[qi]] if cand_idx[qi] else np.zeros(0, np.float32)
+                out.append(select_adversarial(candidates[qi], cand_scores, pos_scores, self.margin, top_k))
         return out
 
     # ------------------------------------------------------------------ ANCE refresh
@@ -119,9 +125,13 @@ class ANCEMiner:
         """Re-encode the corpus with the CURRENT student and rebuild the exact index in HBM."""
         from .index import FAISSIndexBuilder
 
-        embs = np.asarray(self.student.encode_documents(list(corpus_texts)))
-        index = FAISSIndexBuilder(embedding_dim=embs.shape[1], index_type="Flat", metric="ip",
-                                  device=device or getattr(self.student, "device", None))
+        dev = device or getattr(self.student, "device", None)
+        encode_device = getattr(self.student, "encode_documents_device", None)
+        if encode_device is not None:
+            embs = encode_device(list(corpus_texts))      # embeddings stay in HBM: encoder output -> index tiles
+        else:
+            embs = np.asarray(self.student.encode_documents(list(corpus_texts)))
+        index = FAISSIndexBuilder(embedding_dim=int(embs.shape[1]), index_type="Flat", metric="ip", device=dev)
         index.add(embs)
         self._index, self._corpus_ids = index, list(corpus_ids)
         return index

@@ -73,9 +73,13 @@ def build_sharded(model, parquet_path: Union[str, Path], output_dir: Union[str, 
     builder = factory(embedding_dim, metric, device, lo)
     builder.reserve(max(hi - lo, 1))
     slab = max(batch_size, 65536)   # stream: a multi-million-passage shard never needs one host matrix
+    on_device = getattr(model, "encode_documents_device", None)   # embeddings go encoder -> index tiles inside HBM
     for a in range(lo, hi, slab):
         b = min(a + slab, hi)
-        builder.add(model.encode_documents(texts[a:b], batch_size=batch_size, show_progress=show_progress))
+        if on_device is not None:
+            builder.add(on_device(texts[a:b], batch_size=batch_size))
+        else:
+            builder.add(model.encode_documents(texts[a:b], batch_size=batch_size, show_progress=show_progress))
     builder.doc_ids = ids[lo:hi]
     builder.doc_texts = dict(zip(ids[lo:hi], texts[lo:hi]))
     builder.shard_info = {"rank": rank, "world_size": world, "n_total": n}
