@@ -309,6 +309,15 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmArgs p) {
       }
 #endif
     }
+#ifdef SSKD_GEMM256_ABL_NOEPI   // timing ablation (tools/gemm_probe.py): no epilogue
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) asm volatile("" ::"v"(acc[i][j]));
+    m0 = m1;
+    n0 = n1;
+    continue;
+#endif
     // epilogue: acc[i][j][e] = C[m0 + 128 wr + 16 i + 4 fq + e][n0 + WN wc + 16 j + fr]; each wave turns 16 rows at a
     // time through its own slice of LDS into 16-byte row segments (the next tile's DMA is already in flight)
     float bias[NREP];

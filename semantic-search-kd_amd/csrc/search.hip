@@ -774,6 +774,11 @@ static_assert(BSTEPS % BGROUP == 0 && BGROUPS % SCREEN_RING == 0 && SCREEN_RING 
 // x 2^-24 even if every internal add truncated); 3 x 384 x 2^-24 (1 + 2^-8)^2 = 6.9e-5, rounded up generously
 constexpr float SCREEN_ACC_SLACK = 1.0e-4f;
 constexpr int SCREEN_MAX_CAND = 256;             // candidates re-scored per query (one per thread)
+// The in-call exact fallback holds EVERY query, in two launches: the first SCREEN_FALLBACK_TIER1 fallback queries go to a
+// launch planned for that many (a few query blocks spread over many corpus slices: a handful of unproven queries -
+// the usual case - still fills the chip), the rest to a launch planned for nq - TIER1 (only duplicate-flooded corpora
+// ever get there).  Both read their actual query count from device memory; with none, every workgroup exits at once.
+constexpr int SCREEN_FALLBACK_TIER1 = 1024;
 constexpr int SCREEN_MAX_ENTRIES = 4096;         // list entries of one query staged in LDS
 constexpr int SCREEN_CUS = 256;                  // MI355X: the launch geometry is planned in whole rounds of the chip
 
@@ -1258,6 +1263,14 @@ __global__ __launch_bounds__(64) void screen_finalize_kernel(ScreenFinalParams p
     }
     bs = s; bi = i; have = true;
   }
+}
+
+// fb_count[0] = queries handed to the exact fallback; tier 1 answers the first SCREEN_FALLBACK_TIER1 of them with a
+// launch geometry made for FEW queries, tier 2 the rest: [1] = min(count, TIER1), [2] = max(count - TIER1, 0)
+__global__ void screen_fallback_tiers_kernel(int* __restrict__ fb_count, int tier1) {
+  const int n = fb_count[0];
+  fb_count[1] = n < tier1 ? n : tier1;
+  fb_count[2] = n > tier1 ? n - tier1 : 0;
 }
 
 __global__ __launch_bounds__(256) void screen_scatter_kernel(const int* __restrict__ fb_count, const int* __restrict__ fb_qid,
@@ -1883,8 +1896,10 @@ struct ScreenWs {
   float* fb_queries;
   float* fb_scores;
   int64_t* fb_ids;
-  void* exact_ws;
+  void* exact_ws;      // tier 1 (<= SCREEN_FALLBACK_TIER1 queries)
   size_t exact_bytes;
+  void* exact_ws2;     // tier 2 (the rest; absent when nq <= SCREEN_FALLBACK_TIER1)
+  size_t exact_bytes2;
   size_t bytes;
 };
 
@@ -1907,8 +1922,11 @@ ScreenWs screen_carve(void* base, const ScreenPlan& pl, int64_t n_rows, int nq, 
   w.fb_queries = static_cast<float*>(take((size_t)nq * DIM * sizeof(float)));
   w.fb_scores = static_cast<float*>(take((size_t)nq * k * sizeof(float)));
   w.fb_ids = static_cast<int64_t*>(take((size_t)nq * k * sizeof(int64_t)));
-  w.exact_bytes = sskd_index_search_workspace_bytes(n_rows, nq, k);
+  const int tier1 = nq < SCREEN_FALLBACK_TIER1 ? nq : SCREEN_FALLBACK_TIER1;
+  w.exact_bytes = sskd_index_search_workspace_bytes(n_rows, tier1, k);
   w.exact_ws = take(w.exact_bytes);
+  w.exact_bytes2 = nq > tier1 ? sskd_index_search_workspace_bytes(n_rows, nq - tier1, k) : 0;
+  w.exact_ws2 = w.exact_bytes2 ? take(w.exact_bytes2) : nullptr;
   w.bytes = (size_t)(p - static_cast<char*>(base));
   return w;
 }
@@ -2042,9 +2060,17 @@ int sskd_index_search_screened(const float* d_tiled, const void* d_bf16, int64_t
 
   // exact scan for the queries whose candidate band could not be proven complete (usually none:
   // every workgroup of these launches then exits on its first instruction)
-  rc = exact_search_impl(d_tiled, n_rows, w.fb_queries, nq, k, id_offset, w.fb_scores, w.fb_ids,
-                         w.exact_ws, w.exact_bytes, stream, nullptr, nullptr, nullptr, w.fb_count);
+  const int tier1 = nq < SCREEN_FALLBACK_TIER1 ? nq : SCREEN_FALLBACK_TIER1;
+  hipLaunchKernelGGL(screen_fallback_tiers_kernel, dim3(1), dim3(1), 0, st, w.fb_count, tier1);
+  rc = exact_search_impl(d_tiled, n_rows, w.fb_queries, tier1, k, id_offset, w.fb_scores, w.fb_ids,
+                         w.exact_ws, w.exact_bytes, stream, nullptr, nullptr, nullptr, w.fb_count + 1);
   if (rc != SSKD_OK) return rc;
+  if (nq > tier1) {
+    rc = exact_search_impl(d_tiled, n_rows, w.fb_queries + (size_t)tier1 * DIM, nq - tier1, k, id_offset,
+                           w.fb_scores + (size_t)tier1 * k, w.fb_ids + (size_t)tier1 * k, w.exact_ws2, w.exact_bytes2, stream,
+                           nullptr, nullptr, nullptr, w.fb_count + 2);
+    if (rc != SSKD_OK) return rc;
+  }
   hipLaunchKernelGGL(screen_scatter_kernel, dim3(64), dim3(256), 0, st, w.fb_count, w.fb_qid, w.fb_scores, w.fb_ids, k,
                      d_out_scores, d_out_ids);
   if ((rc = sskd::check_launch("screen_scatter_kernel")) != SSKD_OK) return rc;

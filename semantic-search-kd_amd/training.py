@@ -50,26 +50,36 @@ class _EncoderFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        """The HIP backward ACCUMULATES (atomics / +=) straight into ``p.grad`` of every parameter - views of ONE flat fp32
+        buffer that is zeroed with one memset when the gradients were ``None`` - and hands autograd ``None`` for them:
+        no per-call set of ~150 zero-filled buffers (90 MB for e5-small, the dense 30522 x 384 word-embedding gradient
+        included) and no ~150 accumulation kernels when a step calls the encoder more than once (the reference calls
+        ``encode_with_gradients`` 2 x batch_size times per step, src/kd/train.py:176-210)."""
         lib = _native.load()
         module: TrainableEncoder = ctx.module
         ids, mask = ctx.saved_tensors
         B, S = ids.shape
         if ctx.weights_version != module._weights_version:
             raise RuntimeError("parameters changed between forward and backward of encode_with_gradients")
-        grads, gstruct, keep = module._new_grad_buffers()
+        module._attach_grads()
         dout = dout.to(torch.float32).contiguous()
         with torch.cuda.device(ids.device):
             _native.check(lib.sskd_generic_backward(
-                module.cfg_struct, module.w_struct, gstruct, ids.data_ptr(), mask.data_ptr(), B, S, int(ctx.normalize),
+                module.cfg_struct, module.w_struct, module.g_struct, ids.data_ptr(), mask.data_ptr(), B, S, int(ctx.normalize),
                 dout.data_ptr(), ctx.ws.data_ptr(), ctx.ws.numel(),
                 int(torch.cuda.current_stream(ids.device).cuda_stream)))
-        del keep
         ctx.ws = None
-        return (None, None, None, None, *module._grads_in_param_order(grads))
+        return (None, None, None, None) + (None,) * len(module.names)
 
 
 class TrainableEncoder(nn.Module):
-    """fp32 master parameters (HF ``BertModel`` names) + the bf16 device copies the kernels read."""
+    """fp32 master parameters (HF ``BertModel`` names) + the bf16 device copies the kernels read.
+
+    Every parameter is a VIEW of one flat fp32 buffer laid out the way the C-ABI wants it (per layer: Wq, Wk, Wv
+    back to back = the fused [3H, H] QKV matrix, then their biases, ...), and every ``.grad`` a view of a second flat
+    buffer with the same layout.  That makes the per-step housekeeping three launches instead of ~450: ONE cast of the
+    flat master to bf16 + FOUR batched transposes (the backward's W^T operands, all 12 layers per launch) after an
+    optimizer step, ONE memset of the gradients.  Optimizers see ordinary ``nn.Parameter``s."""
 
     def __init__(self, config: BertConfig, state_dict: Dict[str, np.ndarray], device, pos_offset: int = 0) -> None:
         super().__init__()
@@ -77,12 +87,58 @@ class TrainableEncoder(nn.Module):
         self.config = config
         self.device = torch.device(device)
         self.pos_offset = pos_offset
+        H, F, L = config.hidden_size, config.intermediate_size, config.num_hidden_layers
+        # ---- layout (element offsets into the flat buffers) ----
+        layer_fields = [  # (hf suffix, shape)
+            ("attention.self.query.weight", (H, H)), ("attention.self.key.weight", (H, H)), ("attention.self.value.weight", (H, H)),
+            ("attention.self.query.bias", (H,)), ("attention.self.key.bias", (H,)), ("attention.self.value.bias", (H,)),
+            ("attention.output.dense.weight", (H, H)), ("attention.output.dense.bias", (H,)),
+            ("attention.output.LayerNorm.weight", (H,)), ("attention.output.LayerNorm.bias", (H,)),
+            ("intermediate.dense.weight", (F, H)), ("intermediate.dense.bias", (F,)),
+            ("output.dense.weight", (H, F)), ("output.dense.bias", (H,)),
+            ("output.LayerNorm.weight", (H,)), ("output.LayerNorm.bias", (H,)),
+        ]
+        self._field_off: Dict[str, int] = {}
+        off = 0
+        for suffix, shape in layer_fields:
+            self._field_off[suffix] = off
+            off += int(np.prod(shape))
+        self._layer_stride = off
+        layout: Dict[str, tuple] = {}
+        for i in range(L):
+            for suffix, shape in layer_fields:
+                layout[f"encoder.layer.{i}.{suffix}"] = (i * self._layer_stride + self._field_off[suffix], shape)
+        off = L * self._layer_stride
+        for name, shape in (("embeddings.word_embeddings.weight", (config.vocab_size, H)),
+                            ("embeddings.position_embeddings.weight", (config.max_position_embeddings, H)),
+                            ("embeddings.token_type_embeddings.weight", (config.type_vocab_size, H)),
+                            ("embeddings.LayerNorm.weight", (H,)), ("embeddings.LayerNorm.bias", (H,))):
+            layout[name] = (off, shape)
+            off += int(np.prod(shape))
+        if H % 8 or F % 8:
+            raise ValueError("hidden / intermediate sizes must be multiples of 8 (16-byte aligned bf16 rows)")
+        self._layout, self._total = layout, off
+        flat = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.names: List[str] = []
         for name, arr in state_dict.items():
             if name.endswith("position_ids") or name.startswith("pooler."):
                 continue
+            if name not in layout:
+                raise KeyError(f"unexpected parameter {name!r}")
+            o, shape = layout[name]
+            if tuple(arr.shape) != tuple(shape):
+                raise ValueError(f"{name}: shape {tuple(arr.shape)} != {tuple(shape)}")
+            flat[o : o + int(np.prod(shape))] = torch.from_numpy(np.ascontiguousarray(arr, np.float32)).reshape(-1).to(self.device)
             self.names.append(name)
-            self.register_parameter(_pname(name), nn.Parameter(torch.from_numpy(np.ascontiguousarray(arr, np.float32)).to(self.device)))
+        missing = set(layout) - set(self.names)
+        if missing:
+            raise KeyError(f"state dict lacks {sorted(missing)[:3]} ...")
+        self._flat = flat
+        for name in self.names:   # parameters share the flat buffer's storage
+            o, shape = layout[name]
+            self.register_parameter(_pname(name), nn.Parameter(flat[o : o + int(np.prod(shape))].view(shape)))
+        self._flat_grad = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self._flat_bf16 = torch.empty(off, dtype=torch.bfloat16, device=self.device)
         self.cfg_struct = _native.GenericConfig(
             config.vocab_size, config.hidden_size, config.num_hidden_layers, config.num_attention_heads,
             config.intermediate_size, config.max_position_embeddings, config.type_vocab_size,
@@ -91,104 +147,109 @@ class TrainableEncoder(nn.Module):
         self._seen_versions: Optional[tuple] = None
         self._keep: list = []
         self.w_struct = None
+        self.g_struct, self._g_layers = self._grad_struct()
 
     def p(self, hf_name: str) -> nn.Parameter:
         return getattr(self, _pname(hf_name))
 
+    def _off(self, layer: int, suffix: str) -> int:
+        return layer * self._layer_stride + self._field_off[suffix]
+
     # -------------------------------------------------------------- device copies
+    def invalidate(self) -> None:
+        """Force the bf16 copies to be rebuilt at the next forward.  Needed only after parameters were changed through
+        ``p.data`` / ``torch.no_grad`` tricks that do not bump the tensors' version counters (in-place optimizer steps
+        do bump them and are picked up automatically)."""
+        self._seen_versions = None
+
     def _refresh_device_weights(self) -> None:
-        versions = tuple(p._version for p in self.parameters())
+        params = list(self.parameters())
+        for q in params:   # a parameter re-pointed at foreign storage (load_state_dict copies in place and is fine)
+            if q.untyped_storage().data_ptr() != self._flat.untyped_storage().data_ptr():
+                raise RuntimeError("a parameter no longer lives in the flat master buffer (assign with p.data.copy_ / load_state_dict)")
+        versions = tuple(q._version for q in params)
         if versions == self._seen_versions and self.w_struct is not None:
             return
-        keep = []
+        cfg = self.config
+        H, F, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+        self._flat_bf16.copy_(self._flat)                                   # ONE cast kernel for all parameters
+        bf_base, f_base = self._flat_bf16.data_ptr(), self._flat.data_ptr()
 
-        def bf(t: torch.Tensor) -> int:
-            t = t.detach().to(torch.bfloat16).contiguous()
-            keep.append(t)
-            return t.data_ptr()
+        def transposed(suffix: str, rows: int, cols: int) -> torch.Tensor:   # [L, cols, rows], one launch for all layers
+            w = self._flat_bf16.as_strided((L, rows, cols), (self._layer_stride, cols, 1), self._field_off[suffix])
+            return w.transpose(1, 2).contiguous()
 
-        def f32(t: torch.Tensor) -> int:
-            t = t.detach().contiguous()
-            keep.append(t)
-            return t.data_ptr()
-
-        L = self.config.num_hidden_layers
+        t_qkv = transposed("attention.self.query.weight", 3 * H, H)
+        t_o = transposed("attention.output.dense.weight", H, H)
+        t_1 = transposed("intermediate.dense.weight", F, H)
+        t_2 = transposed("output.dense.weight", H, F)
         layers = (_native.GenericLayerWeights * max(L, 1))()
         for i in range(L):
-            pre = f"encoder.layer.{i}."
-            wqkv = torch.cat([self.p(pre + f"attention.self.{n}.weight") for n in ("query", "key", "value")], dim=0)
             lw = layers[i]
-            lw.wqkv, lw.wqkv_t = bf(wqkv), bf(wqkv.detach().t())
-            lw.bqkv = f32(torch.cat([self.p(pre + f"attention.self.{n}.bias") for n in ("query", "key", "value")]))
-            for hf, short in (("attention.output.dense", "wo"), ("intermediate.dense", "w1"), ("output.dense", "w2")):
-                w = self.p(pre + hf + ".weight")
-                setattr(lw, short, bf(w))
-                setattr(lw, short + "_t", bf(w.detach().t()))
-            lw.bo = f32(self.p(pre + "attention.output.dense.bias"))
-            lw.b1 = f32(self.p(pre + "intermediate.dense.bias"))
-            lw.b2 = f32(self.p(pre + "output.dense.bias"))
-            lw.ln1_g, lw.ln1_b = f32(self.p(pre + "attention.output.LayerNorm.weight")), f32(self.p(pre + "attention.output.LayerNorm.bias"))
-            lw.ln2_g, lw.ln2_b = f32(self.p(pre + "output.LayerNorm.weight")), f32(self.p(pre + "output.LayerNorm.bias"))
+            bf = lambda sfx: bf_base + 2 * self._off(i, sfx)    # noqa: E731
+            f32 = lambda sfx: f_base + 4 * self._off(i, sfx)    # noqa: E731
+            lw.wqkv, lw.wqkv_t = bf("attention.self.query.weight"), t_qkv[i].data_ptr()
+            lw.bqkv = f32("attention.self.query.bias")
+            lw.wo, lw.wo_t, lw.bo = bf("attention.output.dense.weight"), t_o[i].data_ptr(), f32("attention.output.dense.bias")
+            lw.w1, lw.w1_t, lw.b1 = bf("intermediate.dense.weight"), t_1[i].data_ptr(), f32("intermediate.dense.bias")
+            lw.w2, lw.w2_t, lw.b2 = bf("output.dense.weight"), t_2[i].data_ptr(), f32("output.dense.bias")
+            lw.ln1_g, lw.ln1_b = f32("attention.output.LayerNorm.weight"), f32("attention.output.LayerNorm.bias")
+            lw.ln2_g, lw.ln2_b = f32("output.LayerNorm.weight"), f32("output.LayerNorm.bias")
         w = _native.GenericWeights()
-        w.word_emb = bf(self.p("embeddings.word_embeddings.weight"))
-        w.pos_emb = bf(self.p("embeddings.position_embeddings.weight"))
-        w.type_emb = bf(self.p("embeddings.token_type_embeddings.weight"))
-        w.emb_ln_g = f32(self.p("embeddings.LayerNorm.weight"))
-        w.emb_ln_b = f32(self.p("embeddings.LayerNorm.bias"))
+        w.word_emb = bf_base + 2 * self._layout["embeddings.word_embeddings.weight"][0]
+        w.pos_emb = bf_base + 2 * self._layout["embeddings.position_embeddings.weight"][0]
+        w.type_emb = bf_base + 2 * self._layout["embeddings.token_type_embeddings.weight"][0]
+        w.emb_ln_g = f_base + 4 * self._layout["embeddings.LayerNorm.weight"][0]
+        w.emb_ln_b = f_base + 4 * self._layout["embeddings.LayerNorm.bias"][0]
         w.layers = layers
-        self.w_struct, self._layers_struct, self._keep = w, layers, keep
+        self.w_struct, self._layers_struct, self._keep = w, layers, [t_qkv, t_o, t_1, t_2]
         self._seen_versions = versions
         self._weights_version += 1
 
-    def _new_grad_buffers(self):
-        """Zeroed fp32 buffers in the C-ABI's (fused QKV) shapes + the struct pointing at them."""
-        cfg = self.config
-        H, F, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
-        dev = self.device
-        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)  # noqa: E731
-        g = {"word": z(cfg.vocab_size, H), "pos": z(cfg.max_position_embeddings, H), "type": z(cfg.type_vocab_size, H),
-             "emb_g": z(H), "emb_b": z(H), "layers": []}
+    # -------------------------------------------------------------- gradients
+    def _grad_struct(self):
+        L = self.config.num_hidden_layers
+        g_base = self._flat_grad.data_ptr()
         layers = (_native.GenericLayerGrads * max(L, 1))()
         for i in range(L):
-            lg = {"wqkv": z(3 * H, H), "bqkv": z(3 * H), "wo": z(H, H), "bo": z(H), "ln1_g": z(H), "ln1_b": z(H),
-                  "w1": z(F, H), "b1": z(F), "w2": z(H, F), "b2": z(H), "ln2_g": z(H), "ln2_b": z(H)}
-            for k, t in lg.items():
-                setattr(layers[i], k, t.data_ptr())
-            g["layers"].append(lg)
+            at = lambda sfx: g_base + 4 * self._off(i, sfx)    # noqa: E731
+            lg = layers[i]
+            lg.wqkv, lg.bqkv = at("attention.self.query.weight"), at("attention.self.query.bias")
+            lg.wo, lg.bo = at("attention.output.dense.weight"), at("attention.output.dense.bias")
+            lg.ln1_g, lg.ln1_b = at("attention.output.LayerNorm.weight"), at("attention.output.LayerNorm.bias")
+            lg.w1, lg.b1 = at("intermediate.dense.weight"), at("intermediate.dense.bias")
+            lg.w2, lg.b2 = at("output.dense.weight"), at("output.dense.bias")
+            lg.ln2_g, lg.ln2_b = at("output.LayerNorm.weight"), at("output.LayerNorm.bias")
         s = _native.GenericGrads()
-        s.word_emb, s.pos_emb, s.type_emb = g["word"].data_ptr(), g["pos"].data_ptr(), g["type"].data_ptr()
-        s.emb_ln_g, s.emb_ln_b = g["emb_g"].data_ptr(), g["emb_b"].data_ptr()
+        s.word_emb = g_base + 4 * self._layout["embeddings.word_embeddings.weight"][0]
+        s.pos_emb = g_base + 4 * self._layout["embeddings.position_embeddings.weight"][0]
+        s.type_emb = g_base + 4 * self._layout["embeddings.token_type_embeddings.weight"][0]
+        s.emb_ln_g = g_base + 4 * self._layout["embeddings.LayerNorm.weight"][0]
+        s.emb_ln_b = g_base + 4 * self._layout["embeddings.LayerNorm.bias"][0]
         s.layers = layers
-        return g, s, layers
+        return s, layers
 
-    def _grads_in_param_order(self, g) -> List[torch.Tensor]:
-        H = self.config.hidden_size
-        out = []
-        for name in self.names:
-            if name == "embeddings.word_embeddings.weight":
-                out.append(g["word"])
-            elif name == "embeddings.position_embeddings.weight":
-                out.append(g["pos"])
-            elif name == "embeddings.token_type_embeddings.weight":
-                out.append(g["type"])
-            elif name == "embeddings.LayerNorm.weight":
-                out.append(g["emb_g"])
-            elif name == "embeddings.LayerNorm.bias":
-                out.append(g["emb_b"])
-            else:
-                parts = name.split(".")
-                lg = g["layers"][int(parts[2])]
-                rest, kind = ".".join(parts[3:-1]), parts[-1]
-                qkv = {"attention.self.query": 0, "attention.self.key": 1, "attention.self.value": 2}
-                if rest in qkv:
-                    src = lg["wqkv"] if kind == "weight" else lg["bqkv"]
-                    out.append(src[qkv[rest] * H : (qkv[rest] + 1) * H])
-                else:
-                    key = {"attention.output.dense": ("wo", "bo"), "intermediate.dense": ("w1", "b1"),
-                           "output.dense": ("w2", "b2"), "attention.output.LayerNorm": ("ln1_g", "ln1_b"),
-                           "output.LayerNorm": ("ln2_g", "ln2_b")}[rest]
-                    out.append(lg[key[0] if kind == "weight" else key[1]])
-        return out
+    def _attach_grads(self) -> None:
+        """Make every ``p.grad`` the matching view of the flat gradient buffer.  Gradients that were ``None`` (after
+        ``zero_grad(set_to_none=True)`` or before the first step) start from ONE memset; gradients that already are our
+        views keep their contents (autograd semantics: backward accumulates); foreign ``.grad`` tensors are folded in."""
+        params = [self.p(n) for n in self.names]
+        ours = [q.grad is not None and q.grad.untyped_storage().data_ptr() == self._flat_grad.untyped_storage().data_ptr()
+                for q in params]
+        if all(ours):
+            return
+        if not any(ours):
+            self._flat_grad.zero_()
+        for name, q, mine in zip(self.names, params, ours):
+            if mine:
+                continue
+            o, shape = self._layout[name]
+            view = self._flat_grad[o : o + int(np.prod(shape))].view(shape)
+            if any(ours):
+                view.zero_()                      # mixed state: this slot was dropped, the others are live
+            if q.grad is not None:
+                view.add_(q.grad)                 # a gradient somebody else put there
+            q.grad = view
 
     # -------------------------------------------------------------- forward
     def forward(self, input_ids, attention_mask=None, normalize: bool = True) -> torch.Tensor:
