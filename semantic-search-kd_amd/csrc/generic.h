@@ -56,7 +56,8 @@ int launch_add_ln_fwd(const bf16_t* a, const bf16_t* b, const float* gamma, cons
 // dz = LN backward of dy; dgamma / dbeta (fp32 [H]) are ACCUMULATED (atomics); dz_colsum (optional, fp32 [H]) +=
 // column sums of dz (the bias gradient of the product whose output was normalised).
 int launch_ln_bwd(const bf16_t* dy, const bf16_t* z, const float* mean, const float* rstd, const float* gamma,
-                  int64_t M, int H, bf16_t* dz, float* dgamma, float* dbeta, hipStream_t st, float* dz_colsum = nullptr);
+                  int64_t M, int H, bf16_t* dz, float* dgamma, float* dbeta, hipStream_t st, float* dz_colsum = nullptr,
+                  const bf16_t* dy2 = nullptr);   // incoming gradient = dy + dy2 (residual branch), dz may alias either
 
 // Inference attention, fused (no score matrix in memory): for every (batch row, head)
 //   ctx[b, :, h*DH : (h+1)*DH] = softmax(scale * Q K^T + (key masked ? -inf : 0)) V
@@ -81,6 +82,8 @@ int launch_softmax_bwd(bf16_t* dP, const bf16_t* P, int64_t rows, int S, float s
 
 int launch_gelu_fwd(const bf16_t* u, bf16_t* h, int64_t n, hipStream_t st);
 int launch_gelu_bwd(const bf16_t* u, const bf16_t* dh, bf16_t* du, int64_t n, hipStream_t st);
+// the same over a [M, F] matrix, plus db[c] += column sums of du (the bias gradient of the product that made u)
+int launch_gelu_bwd_colsum(const bf16_t* u, const bf16_t* dh, bf16_t* du, float* db, int64_t M, int F, hipStream_t st);
 
 // db[N] += sum_m dY[m, N]  (fp32, accumulated with atomics)
 int launch_colsum(const bf16_t* dY, int64_t M, int N, int64_t ld, float* db, hipStream_t st);

@@ -961,10 +961,13 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const bf16_t* __restric
 }
 
 constexpr int LN_BWD_ROWS = 64;  // rows per workgroup (16 per wave)
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ z,
+// dy2 (optional): the incoming gradient is dy + dy2 (the residual branch's share), added in fp32 on the fly - the
+// separate add kernel and its 3 passes over [tokens, hidden] are gone.  dz may alias dy or dy2: a wave reads its whole
+// row into registers before it writes.
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, const bf16_t* dy2, const bf16_t* __restrict__ z,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, int64_t M, int H,
-                                                     bf16_t* __restrict__ dz, float* __restrict__ dgamma,
+                                                     bf16_t* dz, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, float* __restrict__ dz_colsum) {
   __shared__ float red[3][1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -992,9 +995,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       if (c < H) {
         const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dy + row * H + c);
         const bf16x8 zv = *reinterpret_cast<const bf16x8*>(z + row * H + c);
+        bf16x8 d2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d2[j] = (bf16_t)0.f;
+        if (dy2) d2 = *reinterpret_cast<const bf16x8*>(dy2 + row * H + c);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float d = (float)dv[j];
+          const float d = (float)dv[j] + (float)d2[j];
           xh[i][j] = ((float)zv[j] - mu) * rs;
           g[i][j] = d * gm[i][j];
           dg[i][j] += d * xh[i][j];
@@ -1163,6 +1170,35 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict_
     }
     reinterpret_cast<bf16x8*>(du)[i] = o;
   }
+}
+
+// du = dh * gelu'(u) over a [M, F] matrix AND db[c] += sum_r du[r][c] (the FFN1 bias gradient: the separate column-sum
+// pass re-read all of du).  Thread = one 8-column chunk, rows blockIdx.x, + gridDim.x, ...: a row's chunks are 16-byte
+// loads by consecutive threads; the column sums of du AS STORED (bf16) stay in registers, one atomic per column and
+// workgroup row-walk at the end.
+__global__ __launch_bounds__(256) void gelu_bwd_colsum_kernel(const bf16_t* __restrict__ u, const bf16_t* __restrict__ dh,
+                                                              bf16_t* __restrict__ du, float* __restrict__ db, int64_t M,
+                                                              int F8) {
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= F8) return;
+  float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int64_t r = blockIdx.x; r < M; r += gridDim.x) {
+    const int64_t i = r * F8 + c;
+    const bf16x8 x = reinterpret_cast<const bf16x8*>(u)[i];
+    const bf16x8 g = reinterpret_cast<const bf16x8*>(dh)[i];
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float f = (float)x[j];
+      const float cdf = 0.5f * (1.0f + erff(f * 0.70710678118654752f));
+      const float pdf = 0.3989422804014327f * __expf(-0.5f * f * f);
+      o[j] = (bf16_t)((float)g[j] * (cdf + f * pdf));
+      s8[j] += (float)o[j];
+    }
+    reinterpret_cast<bf16x8*>(du)[i] = o;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) atomicAdd(db + 8 * c + j, s8[j]);
 }
 
 __global__ __launch_bounds__(256) void add_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
@@ -1513,10 +1549,11 @@ int launch_add_ln_fwd(const bf16_t* a, const bf16_t* b, const float* gamma, cons
 }
 
 int launch_ln_bwd(const bf16_t* dy, const bf16_t* z, const float* mean, const float* rstd, const float* gamma,
-                  int64_t M, int H, bf16_t* dz, float* dgamma, float* dbeta, hipStream_t st, float* dz_colsum) {
+                  int64_t M, int H, bf16_t* dz, float* dgamma, float* dbeta, hipStream_t st, float* dz_colsum,
+                  const bf16_t* dy2) {
   SSKD_REQUIRE(H % 8 == 0 && H <= 1024, "layernorm: hidden=%d must be a multiple of 8, at most 1024", H);
   if (M == 0) return SSKD_OK;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)sskd::ceil_div(M, LN_BWD_ROWS)), dim3(256), 0, st, dy, z, mean, rstd,
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)sskd::ceil_div(M, LN_BWD_ROWS)), dim3(256), 0, st, dy, dy2, z, mean, rstd,
                      gamma, M, H, dz, dgamma, dbeta, dz_colsum);
   return sskd::check_launch("ln_bwd_kernel");
 }
@@ -1549,6 +1586,17 @@ int launch_gelu_bwd(const bf16_t* u, const bf16_t* dh, bf16_t* du, int64_t n, hi
   if (n == 0) return SSKD_OK;
   hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid1d(n / 8)), dim3(256), 0, st, u, dh, du, n / 8);
   return sskd::check_launch("gelu_bwd_kernel");
+}
+
+int launch_gelu_bwd_colsum(const bf16_t* u, const bf16_t* dh, bf16_t* du, float* db, int64_t M, int F, hipStream_t st) {
+  SSKD_REQUIRE(F % 8 == 0, "gelu: width must be a multiple of 8");
+  if (M == 0 || F == 0) return SSKD_OK;
+  const int F8 = F / 8;
+  const unsigned gy = (unsigned)sskd::ceil_div(F8, 256);
+  unsigned gx = (unsigned)(M < 2048 / gy ? M : 2048 / gy);   // ~2048 workgroups; every thread walks M / gx rows
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(gelu_bwd_colsum_kernel, dim3(gx, gy), dim3(256), 0, st, u, dh, du, db, M, F8);
+  return sskd::check_launch("gelu_bwd_colsum_kernel");
 }
 
 int launch_colsum(const bf16_t* dY, int64_t M, int N, int64_t ld, float* db, hipStream_t st) {

@@ -327,36 +327,37 @@ int forward_all(const sskd_generic_config* cfg, const sskd_generic_weights* w, c
   return SSKD_OK;
 }
 
-// last stage of a layer's backward: qkv = x Wqkv^T + bqkv, plus the residual branch of LN1; result in sv.tH1
+// last stage of a layer's backward: qkv = x Wqkv^T + bqkv.  The layer's input gradient is sv.tH1 + dz1 (dz1 = the
+// residual branch of LN1, in sv.tH0): the SUM is formed by the consumer - the LayerNorm backward that opens the layer
+// below (or the embedding LayerNorm's) - not by a pass of its own.
 int layer_backward_qkv(const Dims& d, const sskd_generic_layer_weights& lw, const sskd_generic_layer_grads& gw,
-                       const bf16_t* x_in, Saved& sv, bf16_t* dqkv, const bf16_t* dz1, hipStream_t st) {
+                       const bf16_t* x_in, Saved& sv, bf16_t* dqkv, hipStream_t st) {
   const int H = d.H;
   const int64_t M = d.M;
   TRY(weight_grad(dqkv, 3 * H, x_in, H, M, gw.wqkv, gw.bqkv, sv.tA, sv.tB, st));
   TRY(gemm(dqkv, 3 * H, static_cast<const bf16_t*>(lw.wqkv_t), 3 * H, sv.tH1, H, M, H, 3 * H, nullptr, false, false, st));
-  TRY(launch_add(sv.tH1, dz1, sv.tH1, M * H, st));        // + residual branch of LN1
   return SSKD_OK;
 }
 
-// ---- backward of one layer: dx2 (gradient of the layer output) -> dx (gradient of its input) ----
-// dx2 is overwritten; the result is returned in sv.tH1.
+// ---- backward of one layer: dx2 + dx2b (gradient of the layer output; dx2b optional) -> gradient of its input ----
+// The result is sv.tH1 + sv.tH0 (the caller hands both to the next consumer).
 int layer_backward(const Dims& d, const sskd_generic_layer_weights& lw, const sskd_generic_layer_grads& gw,
-                   const bf16_t* x_in, const int32_t* mask, const LayerSaved& ls, Saved& sv, bf16_t* dx2, hipStream_t st) {
+                   const bf16_t* x_in, const int32_t* mask, const LayerSaved& ls, Saved& sv, const bf16_t* dx2,
+                   const bf16_t* dx2b, hipStream_t st) {
   const int H = d.H, S = d.S, DH = d.DH, NH = d.NH, F = d.F;
   const int64_t M = d.M;
-  bf16_t* dz2 = sv.tH0;
-  TRY(launch_ln_bwd(dx2, ls.z2, ls.mean2, ls.rstd2, lw.ln2_g, M, H, dz2, gw.ln2_g, gw.ln2_b, st, gw.b2));  // + db2
+  bf16_t* dz2 = sv.tH0;   // may alias dx2b: ln_bwd reads a row before it writes it
+  TRY(launch_ln_bwd(dx2, ls.z2, ls.mean2, ls.rstd2, lw.ln2_g, M, H, dz2, gw.ln2_g, gw.ln2_b, st, gw.b2, dx2b));  // + db2
   // y = hmid W2^T + b2
   TRY(weight_grad(dz2, H, ls.hmid, F, M, gw.w2, nullptr, sv.tA, sv.tB, st));
   TRY(gemm(dz2, H, static_cast<const bf16_t*>(lw.w2_t), H, sv.tF0, F, M, F, H, nullptr, false, false, st));  // dhmid
-  TRY(launch_gelu_bwd(ls.u, sv.tF0, sv.tF0, M * F, st));  // du (in place)
+  TRY(launch_gelu_bwd_colsum(ls.u, sv.tF0, sv.tF0, gw.b1, M, F, st));  // du (in place) + db1
   // u = x1 W1^T + b1
-  TRY(weight_grad(sv.tF0, F, ls.x1, H, M, gw.w1, gw.b1, sv.tA, sv.tB, st));
+  TRY(weight_grad(sv.tF0, F, ls.x1, H, M, gw.w1, nullptr, sv.tA, sv.tB, st));
   bf16_t* dx1 = sv.tH1;
   TRY(gemm(sv.tF0, F, static_cast<const bf16_t*>(lw.w1_t), F, dx1, H, M, H, F, nullptr, false, false, st));
-  TRY(launch_add(dx1, dz2, dx1, M * H, st));           // + residual branch of LN2
-  bf16_t* dz1 = sv.tH0;
-  TRY(launch_ln_bwd(dx1, ls.z1, ls.mean1, ls.rstd1, lw.ln1_g, M, H, dz1, gw.ln1_g, gw.ln1_b, st, gw.bo));  // + dbo
+  bf16_t* dz1 = sv.tH0;   // aliases dz2, the residual branch of LN2 that this call adds to dx1 on the fly
+  TRY(launch_ln_bwd(dx1, ls.z1, ls.mean1, ls.rstd1, lw.ln1_g, M, H, dz1, gw.ln1_g, gw.ln1_b, st, gw.bo, dz2));  // + dbo
   // attn_out = ctx Wo^T + bo
   TRY(weight_grad(dz1, H, ls.ctx, H, M, gw.wo, nullptr, sv.tA, sv.tB, st));
   bf16_t* dctx = sv.tH2;
@@ -366,7 +367,7 @@ int layer_backward(const Dims& d, const sskd_generic_layer_weights& lw, const ss
   if (ls.lse) {
     bf16_t* dqkv_f = sv.t3H;
     TRY(launch_attention_bwd(ls.qkv, mask, ls.ctx, dctx, ls.lse, d.B, S, NH, DH, 1.0f / sqrtf((float)DH), dqkv_f, st));
-    return layer_backward_qkv(d, lw, gw, x_in, sv, dqkv_f, dz1, st);
+    return layer_backward_qkv(d, lw, gw, x_in, sv, dqkv_f, st);
   }
   const int64_t bS3H = (int64_t)S * 3 * H, bPP = (int64_t)NH * S * S, hPP = (int64_t)S * S;
   // dP = dctx_bh V_bh^T
@@ -481,7 +482,7 @@ int layer_backward(const Dims& d, const sskd_generic_layer_weights& lw, const ss
   gk.B = sv.tA;
   gk.C = dqkv + H;
   TRY(launch_gemm_nt(gk, st));
-  return layer_backward_qkv(d, lw, gw, x_in, sv, dqkv, dz1, st);
+  return layer_backward_qkv(d, lw, gw, x_in, sv, dqkv, st);
 }
 
 // Cross-encoder head, one workgroup per sequence, ALL in fp32 (RobertaClassificationHead with one label):
@@ -574,19 +575,21 @@ int sskd_generic_backward(const sskd_generic_config* cfg, const sskd_generic_wei
                    (cfg->layers == 0 || grads->layers),
                "generic_backward: null gradient pointer");
   hipStream_t st = sskd::as_stream(stream);
-  bf16_t* dx = sv.tH2;  // gradient flowing into the current layer's output
-  TRY(launch_pool_bwd(d_dout, sv.pooled, d_mask, B, S, d.H, normalize, dx, st));
+  // gradient flowing into the current layer's output = dx + dxb (dxb: the residual share, null at the top)
+  const bf16_t* dx = sv.tH2;
+  const bf16_t* dxb = nullptr;
+  TRY(launch_pool_bwd(d_dout, sv.pooled, d_mask, B, S, d.H, normalize, sv.tH2, st));
   for (int l = d.L - 1; l >= 0; --l) {
     const sskd_generic_layer_weights& lw = w->layers[l];
     SSKD_REQUIRE(lw.wqkv_t && lw.wo_t && lw.w1_t && lw.w2_t, "generic_backward: layer %d lacks transposed weights", l);
     const bf16_t* x_in = l == 0 ? sv.x0 : sv.layer[l - 1].x2;
-    TRY(layer_backward(d, lw, grads->layers[l], x_in, d_mask, sv.layer[l], sv, dx, st));
-    // result in tH1 -> becomes the next (lower) layer's dx2; keep it out of the scratch that layer uses first
-    if (hipMemcpyAsync(sv.tH2, sv.tH1, (size_t)d.M * d.H * sizeof(bf16_t), hipMemcpyDeviceToDevice, st) != hipSuccess)
-      return sskd::fail(SSKD_ERR_HIP, "generic_backward: device copy failed");
-    dx = sv.tH2;
+    TRY(layer_backward(d, lw, grads->layers[l], x_in, d_mask, sv.layer[l], sv, dx, dxb, st));
+    // the layer's input gradient is tH1 + tH0: the layer below consumes both in its first kernel (which only READS tH1
+    // and rewrites tH0 row by row), so nothing is copied and nothing is added in a pass of its own
+    dx = sv.tH1;
+    dxb = sv.tH0;
   }
-  TRY(launch_ln_bwd(dx, sv.z0, sv.mean0, sv.rstd0, w->emb_ln_g, d.M, d.H, sv.tH0, grads->emb_ln_g, grads->emb_ln_b, st));
+  TRY(launch_ln_bwd(dx, sv.z0, sv.mean0, sv.rstd0, w->emb_ln_g, d.M, d.H, sv.tH0, grads->emb_ln_g, grads->emb_ln_b, st, nullptr, dxb));
   return launch_embed_bwd(d_ids, d_mask, sv.tH0, B, S, d.H, cfg->vocab_size, cfg->pos_offset, grads->word_emb,
                           grads->pos_emb, grads->type_emb, st);
 }
