@@ -6,6 +6,7 @@ namespace sskd_generic {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmArgs p) {
         for (int i = 0; i < 8; ++i)
 #pragma unroll
           for (int j = 0; j < NREP; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[kk][j], a[kk][i], acc[i][j], 0, 0, 0);   // C^T tile: see the epilogue
       __builtin_amdgcn_s_setprio(0);
 #else
 #pragma unroll
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmArgs p) {
         for (int i = 0; i < 8; ++i)
 #pragma unroll
           for (int j = 0; j < NREP; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
 #ifdef SSKD_GEMM256_SETPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -318,21 +319,32 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmArgs p) {
     n0 = n1;
     continue;
 #endif
-    // epilogue: acc[i][j][e] = C[m0 + 128 wr + 16 i + 4 fq + e][n0 + WN wc + 16 j + fr]; each wave turns 16 rows at a
-    // time through its own slice of LDS into 16-byte row segments (the next tile's DMA is already in flight)
-    float bias[NREP];
+    // epilogue.  The MFMAs above take the B fragments AS THE A OPERAND (they compute the transposed 16 x 16 tile), so
+    // acc[i][j][e] = C[m0 + 128 wr + 16 i + fr][n0 + WN wc + 16 j + 4 fq + e]: a lane holds FOUR CONSECUTIVE COLUMNS of one
+    // row - one 8-byte LDS store per tile instead of four 2-byte ones (+3..9 % on the K = 384 products).  Each wave turns
+    // 16 rows at a time through its own slice of LDS into 16-byte row segments (the next tile's DMA is already in
+    // flight).  Measured and NOT kept (tools/gemm_probe.py, gpurun_out/r03_gemm3.log): the same epilogue straight from
+    // registers (v_permlane32_swap pairs -> 16-byte stores, no LDS, no waits) is no faster - the epilogue is 28-33 % of
+    // the K = 384 products and 16-20 % of the K = 1024 ones (-DSSKD_GEMM256_ABL_NOEPI) because the matrix pipe idles
+    // while 128 accumulators per lane are biased, converted and stored, not because of the LDS round trip: hiding it
+    // needs a second accumulator set or a second workgroup per CU, i.e. another tile shape.
+    f32x4 bias4[NREP];
 #pragma unroll
-    for (int j = 0; j < NREP; ++j) bias[j] = p.bias ? p.bias[n0 + wc * WN + j * 16 + fr] : 0.f;
+    for (int j = 0; j < NREP; ++j)
+      bias4[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n0 + wc * WN + j * 16 + 4 * fq) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
 #pragma unroll
-      for (int j = 0; j < NREP; ++j)
+      for (int j = 0; j < NREP; ++j) {
+        bf16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float x = p.alpha * acc[i][j][e] + bias[j];
+          float x = p.alpha * acc[i][j][e] + bias4[j][e];
           if (p.act == 1) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
-          wt[(4 * fq + e) * LDW + j * 16 + fr] = (bf16_t)x;
+          o[e] = (bf16_t)x;
         }
+        *reinterpret_cast<bf16x4*>(wt + fr * LDW + j * 16 + 4 * fq) = o;
+      }
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's own LDS writes (wave-private slice)
       __builtin_amdgcn_wave_barrier();
       constexpr int CPR = WN / 8;          // 16-byte segments per row: 8 or 4
@@ -608,7 +620,6 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnArgs p) {
   for (int t = 0; t < DT; ++t)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
       bf16x4 w;
 #pragma unroll
       for (int e = 0; e < 4; ++e) w[e] = (bf16_t)(o[t][4 * g + e] * inv);
@@ -1173,19 +1184,20 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict_
 }
 
 // du = dh * gelu'(u) over a [M, F] matrix AND db[c] += sum_r du[r][c] (the FFN1 bias gradient: the separate column-sum
-// pass re-read all of du).  Thread = one 8-column chunk, rows blockIdx.x, + gridDim.x, ...: a row's chunks are 16-byte
-// loads by consecutive threads; the column sums of du AS STORED (bf16) stay in registers, one atomic per column and
-// workgroup row-walk at the end.
-__global__ __launch_bounds__(256) void gelu_bwd_colsum_kernel(const bf16_t* __restrict__ u, const bf16_t* __restrict__ dh,
-                                                              bf16_t* __restrict__ du, float* __restrict__ db, int64_t M,
-                                                              int F8) {
-  const int c = blockIdx.y * 256 + threadIdx.x;
-  if (c >= F8) return;
+// pass re-read all of du).  Workgroup = RY row-lanes x F / 8 column chunks (a row's chunks are 16-byte loads by
+// consecutive threads); a thread walks rows blockIdx.x RY + ry, + gridDim.x RY, ... two at a time, keeps the column sums
+// of du AS STORED (bf16) in registers; the row-lanes meet in LDS and the workgroup adds ONCE per column: 512
+// workgroups x F atomics per call (2 048 x F on the same F addresses ran 5x slower than the unfused pair).
+constexpr int GELU_CS_BLOCKS = 512;
+__global__ __launch_bounds__(1024) void gelu_bwd_colsum_kernel(const bf16_t* __restrict__ u, const bf16_t* __restrict__ dh,
+                                                               bf16_t* __restrict__ du, float* __restrict__ db, int64_t M,
+                                                               int F8, int RY) {
+  extern __shared__ float gcs_part[];   // [F8 * 8]
+  const int c = threadIdx.x % F8, ry = threadIdx.x / F8;
+  for (int i = threadIdx.x; i < F8 * 8; i += blockDim.x) gcs_part[i] = 0.f;
+  __syncthreads();
   float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int64_t r = blockIdx.x; r < M; r += gridDim.x) {
-    const int64_t i = r * F8 + c;
-    const bf16x8 x = reinterpret_cast<const bf16x8*>(u)[i];
-    const bf16x8 g = reinterpret_cast<const bf16x8*>(dh)[i];
+  auto one = [&](const bf16x8& x, const bf16x8& g, int64_t i) {
     bf16x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -1196,9 +1208,26 @@ __global__ __launch_bounds__(256) void gelu_bwd_colsum_kernel(const bf16_t* __re
       s8[j] += (float)o[j];
     }
     reinterpret_cast<bf16x8*>(du)[i] = o;
-  }
+  };
+  if (ry < RY) {
+    const int64_t step = (int64_t)gridDim.x * RY;
+    int64_t r = (int64_t)blockIdx.x * RY + ry;
+    for (; r + step < M; r += 2 * step) {   // two rows in flight
+      const int64_t i0 = r * F8 + c, i1 = (r + step) * F8 + c;
+      const bf16x8 x0 = reinterpret_cast<const bf16x8*>(u)[i0], g0 = reinterpret_cast<const bf16x8*>(dh)[i0];
+      const bf16x8 x1 = reinterpret_cast<const bf16x8*>(u)[i1], g1 = reinterpret_cast<const bf16x8*>(dh)[i1];
+      one(x0, g0, i0);
+      one(x1, g1, i1);
+    }
+    if (r < M) {
+      const int64_t i0 = r * F8 + c;
+      one(reinterpret_cast<const bf16x8*>(u)[i0], reinterpret_cast<const bf16x8*>(dh)[i0], i0);
+    }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) atomicAdd(db + 8 * c + j, s8[j]);
+    for (int j = 0; j < 8; ++j) atomicAdd(&gcs_part[8 * c + j], s8[j]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < F8 * 8; i += blockDim.x) atomicAdd(db + i, gcs_part[i]);
 }
 
 __global__ __launch_bounds__(256) void add_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
@@ -1592,10 +1621,16 @@ int launch_gelu_bwd_colsum(const bf16_t* u, const bf16_t* dh, bf16_t* du, float*
   SSKD_REQUIRE(F % 8 == 0, "gelu: width must be a multiple of 8");
   if (M == 0 || F == 0) return SSKD_OK;
   const int F8 = F / 8;
-  const unsigned gy = (unsigned)sskd::ceil_div(F8, 256);
-  unsigned gx = (unsigned)(M < 2048 / gy ? M : 2048 / gy);   // ~2048 workgroups; every thread walks M / gx rows
-  if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(gelu_bwd_colsum_kernel, dim3(gx, gy), dim3(256), 0, st, u, dh, du, db, M, F8);
+  if (F8 > 512) {   // wide FFNs: the plain pair
+    int rc = launch_gelu_bwd(u, dh, du, M * F, st);
+    return rc != SSKD_OK ? rc : launch_colsum(du, M, F, F, db, st);
+  }
+  const int RY = 1024 / F8 > 0 ? 1024 / F8 : 1;   // 5 row-lanes at F = 1536 (960 threads)
+  const int threads = ((F8 * RY + 63) / 64) * 64;
+  int64_t blocks = sskd::ceil_div(M, (int64_t)RY);
+  if (blocks > GELU_CS_BLOCKS) blocks = GELU_CS_BLOCKS;
+  hipLaunchKernelGGL(gelu_bwd_colsum_kernel, dim3((unsigned)blocks), dim3(threads), (size_t)F * sizeof(float), st, u, dh, du, db,
+                     M, F8, RY);
   return sskd::check_launch("gelu_bwd_colsum_kernel");
 }
 
