@@ -270,6 +270,7 @@ def bench_teacher(device, world: int, steps: int, warmup: int, barrier, pairs: i
     h, f = cfg.hidden_size, cfg.intermediate_size
     flops = pairs * seq_len * cfg.num_hidden_layers * (2.0 * (4 * h * h + 2 * h * f) + 4.0 * seq_len * h)
     tf = flops * steps / dt / 1e12
+    text = bench_teacher_text(teacher) if (world == 1 or dist.get_rank() == 0) else None
     return {
         "value": round(world * pairs * steps / dt, 1),
         "unit": "pairs/s",
@@ -279,4 +280,44 @@ def bench_teacher(device, world: int, steps: int, warmup: int, barrier, pairs: i
         "finite": bool(torch.isfinite(out).all()),
         "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                      "frac": round(tf / MFMA_BF16_PEAK_TF, 4), "algorithmic_flops_per_step": flops},
+        "text": text,
+    }
+
+
+def bench_teacher_text(teacher, n_pairs: int = 4096):
+    """``TeacherModel.score(list of (query, passage) strings)`` end to end - what TeacherMiner and the /search rerank
+    branch call (reference: src/mining/miners.py:135-137, src/serve/app.py:325-326) - on MS MARCO-shaped pairs over a
+    synthetic vocabulary, next to the same launches fed from cached token ids (the GPU-only rate) and the tokenizer
+    alone: the text path should sit within ~15 % of the slower of the two."""
+    from .encoder import build_wordpiece_tokenizer
+
+    vocab = synthetic_vocab(30522)
+    teacher.tokenizer = build_wordpiece_tokenizer(vocab)
+    docs = synthetic_passages(vocab, n_pairs, seed=21)
+    rng = np.random.default_rng(22)
+    whole = [w for w in vocab[1000:4000] if not w.startswith("##") and len(w) > 1]
+    pairs = [(" ".join(rng.choice(whole, size=int(rng.integers(4, 12)))), d) for d in docs]
+    teacher.score(pairs[:512])                                   # warm-up: workspace, tokenizer threads
+    t0 = time.perf_counter()
+    scores = teacher.score(pairs)
+    t_text = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    cached = [teacher.tokenize_pairs(pairs[c : c + teacher.SCORE_CHUNK]) for c in range(0, n_pairs, teacher.SCORE_CHUNK)]
+    t_tok = time.perf_counter() - t0
+    real_tokenize, it = teacher.tokenize_pairs, iter(cached)
+    teacher.tokenize_pairs = lambda chunk: next(it)
+    try:
+        t0 = time.perf_counter()
+        again = teacher.score(pairs)
+        t_gpu = time.perf_counter() - t0
+    finally:
+        teacher.tokenize_pairs = real_tokenize
+    mean_tokens = float(np.mean([m.sum() for _, m in cached])) * len(cached) / n_pairs
+    return {
+        "value": round(n_pairs / t_text, 1), "unit": "pairs/s",
+        "workload": f"TeacherModel.score over {n_pairs} (query, passage) string pairs, mean {mean_tokens:.0f} tokens per pair "
+                    f"(synthetic vocabulary), tokenise + H2D + forward + D2H",
+        "from_cached_token_ids_pairs_per_s": round(n_pairs / t_gpu, 1),
+        "tokenizer_alone_pairs_per_s": round(n_pairs / t_tok, 1),
+        "same_scores_both_ways": bool(np.allclose(scores, again, atol=1e-3)),
     }

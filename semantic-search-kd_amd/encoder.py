@@ -75,7 +75,6 @@ class NativeWordPiece:
                 and norm.get("clean_text", True) is True
                 and pre.get("type") == "BertPreTokenizer"
                 and post.get("type") in ("TemplateProcessing", "BertProcessing")
-                and not spec.get("added_tokens_need_matching")
             )
             if not ok:
                 return None
@@ -85,9 +84,18 @@ class NativeWordPiece:
                 if not 0 <= i < len(toks) or toks[i] is not None or "\n" in t:
                     return None
                 toks[i] = t
-            return cls(toks)
+            self = cls(toks)
+            # the library matches ADDED tokens ([CLS], [SEP], [MASK], ... and any user-added ones) in the RAW text,
+            # before normalisation, and emits their single id; the C++ path would split "[SEP]" into "[", "sep", "]".
+            # Texts containing one of these strings are therefore routed to the library (as non-ASCII texts are).
+            self.added_tokens = tuple(sorted({a["content"] for a in spec.get("added_tokens") or [] if a.get("content")}))
+            return self
         except Exception:
             return None
+
+    def needs_library(self, text: str) -> bool:
+        """True when ``text`` contains a literal added-token string (only the library tokenizes those as one id)."""
+        return any(t in text for t in getattr(self, "added_tokens", ()))
 
     def encode_flat(self, texts: Sequence[str], max_len: int):
         """-> (flat int32 ids, lengths int32, needs_unicode bool[n]) or None when the texts cannot be
@@ -374,15 +382,18 @@ class Mi355xSentenceEncoder:
             m, t0, t1 = s1 - s0, int(cu[s0]), int(cu[s1])
             total = t1 - t0
             cap = ROW_CAPACITY if total >= ROW_CAPACITY else -(-total // 32) * 32
-            st = self._stage(total + (m + 1) + 4 * m)
+            # staging layout (int32 words): [tokens | cu_seqlens (m + 1) | pad to 4 words | table (4 per sequence)]; the
+            # kernels read table entries as 16-byte vectors, so the table starts on a 16-byte boundary
+            tab0 = -(-(total + m + 1) // 4) * 4
+            st = self._stage(tab0 + 4 * m)
             a = st.np
             a[:total] = flat_ids[t0:t1]
             a[total : total + m + 1] = cu[s0 : s1 + 1] - t0
-            table = a[total + m + 1 : total + m + 1 + 4 * m]
+            table = a[tab0 : tab0 + 4 * m]
             n_rows = ctypes.c_int(0)
             _native.check(lib.sskd_pack_plan(lengths[s0:s1].ctypes.data, m, cap, table.ctypes.data, n_rows))
             rows = n_rows.value
-            words = total + (m + 1) + 4 * m
+            words = tab0 + 4 * m
             lane = launch & 1
             with torch.cuda.stream(lanes[lane]):
                 stream = int(lanes[lane].cuda_stream)
@@ -396,7 +407,8 @@ class Mi355xSentenceEncoder:
                                         torch.empty(size, dtype=torch.int32, device=self.device))
                 rows_ids, rows_seg = self._rows[lane]
                 base = st.dev.data_ptr()
-                d_cu, d_table = base + 4 * total, base + 4 * (total + m + 1)
+                d_cu, d_table = base + 4 * total, base + 4 * tab0
+                assert d_table % 16 == 0
                 _native.check(lib.sskd_pack_tokens(base, d_cu, d_table, m, rows, cap, rows_ids.data_ptr(),
                                                    rows_seg.data_ptr(), stream))
                 need = int(lib.sskd_encoder_workspace_bytes(self.weights.cstruct_cfg, rows, cap))
@@ -435,6 +447,11 @@ class Mi355xSentenceEncoder:
             res = self._native_tok.encode_flat(texts, mx)
             if res is not None:
                 flat, lengths, uni = res
+                if getattr(self._native_tok, "added_tokens", ()):
+                    # cheap pre-filter: every BERT added token starts with '[' - only such texts are scanned further
+                    for j, t in enumerate(texts):
+                        if "[" in t and self._native_tok.needs_library(t):
+                            uni[j] = True
                 if not uni.any():
                     return flat, lengths
                 # texts with non-ASCII characters: the Unicode-complete tokenizer, spliced back in place

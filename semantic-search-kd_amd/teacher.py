@@ -289,26 +289,31 @@ class TeacherModel:
         self._dp_enabled, self._dp_group = bool(enabled), group
         return self
 
+    SCORE_CHUNK = 8192   # pairs tokenised at a time: the GPU scores chunk c while the host tokenises chunk c + 1
+
     def _score_local(self, pairs) -> torch.Tensor:
-        """fp32 [n] device tensor of raw logits for this process's pairs: sorted by length, cut into launches by a
-        token budget, written in sorted order and un-permuted once at the end."""
+        """fp32 [n] device tensor of raw logits for this process's pairs.  Pairs are taken in chunks: a chunk is
+        tokenised (the Rust tokenizer, GIL released), sorted by length, cut into launches by a token budget and
+        ENQUEUED - launches are asynchronous, so the GPU works on chunk c while the host tokenises chunk c + 1; nothing
+        synchronises until the caller reads the scores.  Token ids travel as one pinned block per launch."""
         n = len(pairs)
-        if n == 0:
-            return torch.empty(0, dtype=torch.float32, device=self.torch_device)
-        ids, mask = self.tokenize_pairs(pairs)
-        lengths = mask.sum(1)
-        order = np.argsort(-lengths, kind="stable")
-        ids, mask, lengths = ids[order], mask[order], lengths[order]
-        sorted_out = torch.empty(n, dtype=torch.float32, device=self.torch_device)
+        out = torch.empty(n, dtype=torch.float32, device=self.torch_device)
         budget = 64 * 512
-        lo = 0
-        while lo < n:
-            width = max(int(lengths[lo]), 1)
-            rows = max(1, budget // (-(-width // 32) * 32))
-            self.score_token_ids(ids[lo : lo + rows, :width], mask[lo : lo + rows, :width], out=sorted_out[lo : lo + rows])
-            lo += rows
-        out = torch.empty_like(sorted_out)
-        out[torch.from_numpy(order).to(self.torch_device)] = sorted_out
+        for c0 in range(0, n, self.SCORE_CHUNK):
+            chunk = pairs[c0 : c0 + self.SCORE_CHUNK]
+            ids, mask = self.tokenize_pairs(chunk)
+            lengths = mask.sum(1)
+            order = np.argsort(-lengths, kind="stable")
+            ids, mask, lengths = ids[order], mask[order], lengths[order]
+            m = len(chunk)
+            sorted_out = torch.empty(m, dtype=torch.float32, device=self.torch_device)
+            lo = 0
+            while lo < m:
+                width = max(int(lengths[lo]), 1)
+                rows = max(1, budget // (-(-width // 32) * 32))
+                self.score_token_ids(ids[lo : lo + rows, :width], mask[lo : lo + rows, :width], out=sorted_out[lo : lo + rows])
+                lo += rows
+            out[c0 + torch.from_numpy(order).to(self.torch_device)] = sorted_out   # one un-permute per chunk
         return out
 
     def score(self, pairs: Sequence[Union[Tuple[str, str], List[str]]], batch_size: int = 32) -> List[float]:

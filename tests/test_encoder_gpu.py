@@ -251,6 +251,29 @@ def test_text_path_and_student_model(gpu, tmp_path):
     student.cleanup()
 
 
+def test_added_special_tokens_in_raw_text_follow_the_library(gpu):
+    """A tokenizer.json that registers its special tokens as ADDED tokens (every real BERT one does) matches "[SEP]" /
+    "[MASK]" in raw text as ONE id; the C++ WordPiece would split them.  Such texts are routed to the library: the flat
+    id stream of the product's tokenisation equals the library's, text by text, with plain texts still on the C++ path."""
+    from semantic_search_kd_amd.bench_support import synthetic_passages, synthetic_vocab
+    from semantic_search_kd_amd.encoder import Mi355xSentenceEncoder, build_wordpiece_tokenizer
+
+    vocab = synthetic_vocab(4000)
+    tok = build_wordpiece_tokenizer(vocab)
+    tok.add_special_tokens(["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"])
+    cfg = BertConfig(vocab_size=len(vocab), num_hidden_layers=1)
+    enc = Mi355xSentenceEncoder(None, "cuda:0", config=cfg, state_dict=synthetic_state_dict(cfg), tokenizer=tok)
+    assert enc._native_tok is not None and "[SEP]" in enc._native_tok.added_tokens
+    docs = synthetic_passages(vocab, 30, seed=2)
+    texts = docs[:10] + [docs[10] + " [SEP] " + docs[11], "[MASK] " + docs[12], "a [ sep ] b [brackets]", "[CLS]"] + docs[13:]
+    flat, lengths = enc._tokenize_flat(texts)
+    cu = np.concatenate([[0], np.cumsum(lengths)])
+    for i, e in enumerate(tok.encode_batch(texts)):
+        assert flat[cu[i] : cu[i + 1]].tolist() == e.ids, texts[i]
+    sep = vocab.index("[SEP]")
+    assert flat[cu[10] : cu[11]].tolist().count(sep) == 2     # the literal one and the template's
+
+
 def test_model_name_is_never_fetched(gpu):
     with pytest.raises(FileNotFoundError, match="never downloads"):
         StudentModel("intfloat/e5-small-v2", device="cuda:0")

@@ -238,6 +238,21 @@ def test_native_wordpiece_equals_tokenizers_library():
     from tokenizers import Tokenizer, models
 
     assert NativeWordPiece.from_hf(Tokenizer(models.WordPiece({"[UNK]": 0}, unk_token="[UNK]"))) is None
+    # a real BERT tokenizer.json registers its special tokens as ADDED tokens: the library then matches "[SEP]" in raw
+    # text as ONE id, the C++ path would split it - such texts are flagged for the library, everything else still agrees
+    tok2 = build_wordpiece_tokenizer(vocab)
+    tok2.add_special_tokens(["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"])
+    nt2 = NativeWordPiece.from_hf(tok2)
+    assert nt2 is not None and {"[SEP]", "[MASK]", "[CLS]"} <= set(nt2.added_tokens)
+    literal = "first part [SEP] second [MASK] part"
+    assert nt2.needs_library(literal) and not nt2.needs_library("plain [brackets] and [ sep ] text")
+    assert vocab.index("[SEP]") in tok2.encode(literal).ids[1:-1]           # the library: one id
+    plain = texts[:50]
+    flat, lengths, uni = nt2.encode_flat(plain, 512)
+    cu = np.concatenate([[0], np.cumsum(lengths)])
+    for i, e in enumerate(tok2.encode_batch(plain)):
+        if not nt2.needs_library(plain[i]):
+            assert flat[cu[i] : cu[i + 1]].tolist() == e.ids, plain[i]
 
 
 def test_ance_miner_matches_reference_fixture():
