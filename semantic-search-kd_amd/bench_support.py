@@ -284,7 +284,7 @@ def bench_teacher(device, world: int, steps: int, warmup: int, barrier, pairs: i
     }
 
 
-def bench_teacher_text(teacher, n_pairs: int = 4096):
+def bench_teacher_text(teacher, n_pairs: int = 8192):
     """``TeacherModel.score(list of (query, passage) strings)`` end to end - what TeacherMiner and the /search rerank
     branch call (reference: src/mining/miners.py:135-137, src/serve/app.py:325-326) - on MS MARCO-shaped pairs over a
     synthetic vocabulary, next to the same launches fed from cached token ids (the GPU-only rate) and the tokenizer

@@ -289,7 +289,7 @@ class TeacherModel:
         self._dp_enabled, self._dp_group = bool(enabled), group
         return self
 
-    SCORE_CHUNK = 8192   # pairs tokenised at a time: the GPU scores chunk c while the host tokenises chunk c + 1
+    SCORE_CHUNK = 2048   # pairs tokenised at a time: the GPU scores chunk c while the host tokenises chunk c + 1
 
     def _score_local(self, pairs) -> torch.Tensor:
         """fp32 [n] device tensor of raw logits for this process's pairs.  Pairs are taken in chunks: a chunk is
