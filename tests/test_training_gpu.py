@@ -221,3 +221,61 @@ def test_kd_training_step_matches_oracle_and_learns(gpu):
     before = enc.encode_token_ids(d_ids, d_mask).cpu().numpy()
     want = model(d_ids, d_mask).detach().cpu().numpy()
     assert min(_cos(before[i], want[i]) for i in range(9)) > 0.999
+
+
+@pytest.mark.gpu
+def test_kd_step_at_bench_depth_and_geometry_vs_oracle(gpu):
+    """BASELINE cfg 4 as bench.py runs it - the full e5-small-v2 architecture (12 layers), queries of 32 tokens and
+    passages of 256 tokens, (query, positive, 7 negatives) tuples, two encodes -> q . d -> CombinedKDLoss (HIP) ->
+    backward INTO the flat gradient buffer - with 4 tuples instead of 32 so that the CPU oracle chain (oracle encoder
+    under torch autograd + the reference-pinned KD-loss oracle) finishes in seconds.  Loss, scores and every
+    parameter gradient are compared; the accumulation of the two backward calls into one ``.grad`` is part of it."""
+    from semantic_search_kd_amd import CombinedKDLoss
+    from semantic_search_kd_amd.training import TrainableEncoder
+
+    cfg = BertConfig(vocab_size=3000)
+    assert cfg.num_hidden_layers == 12 and cfg.hidden_size == 384
+    sd = synthetic_state_dict(cfg)
+    tuples, docs = 4, 8
+    q_ids, q_mask = enc_oracle.synthetic_token_ids(tuples, 32, seed=51, vocab=3000, lengths=[32, 20, 9, 5])
+    d_ids, d_mask = enc_oracle.synthetic_token_ids(tuples * docs, 256, seed=52, vocab=3000,
+                                                   lengths=[256, 200, 131, 90, 77, 64, 33, 12] * tuples)
+    teacher = np.random.Generator(np.random.PCG64(53)).standard_normal((tuples, docs)).astype(np.float32) * 3.0
+    model = TrainableEncoder(cfg, sd, "cuda:0")
+    loss_fn = CombinedKDLoss()
+    q = model(q_ids, q_mask)
+    d = model(d_ids, d_mask).view(tuples, docs, -1)
+    scores = torch.einsum("th,tdh->td", q, d)
+    out = loss_fn(scores, torch.from_numpy(teacher).cuda())
+    out["loss"].backward()
+    grads = {n: model.p(n).grad.detach().cpu().numpy() for n in model.names}
+    # the gradients live in ONE flat buffer and both backward calls accumulated into it
+    assert all(model.p(n).grad.untyped_storage().data_ptr() == model._flat_grad.untyped_storage().data_ptr() for n in model.names)
+    t = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in sd.items()}
+    qo = enc_oracle.embeddings_torch(t, q_ids, q_mask, 12)
+    do = enc_oracle.embeddings_torch(t, d_ids, d_mask, 12).view(tuples, docs, -1)
+    so = torch.einsum("th,tdh->td", qo, do)
+    ref, ref_ds = kd_oracle.combined(so.detach().numpy(), teacher, loss_fn.current_temperature)
+    so.backward(gradient=torch.from_numpy(ref_ds.astype(np.float32)))
+    assert np.abs(scores.detach().cpu().numpy() - so.detach().numpy()).max() < 1e-2
+    assert abs(float(out["loss"].detach()) - ref["loss"]) < 2e-2 * max(1.0, abs(ref["loss"]))
+    worst, checked = 1.0, 0
+    for name in model.names:
+        refg = t[name].grad.numpy()
+        if "key.bias" in name or np.linalg.norm(refg) < 1e-10:
+            continue
+        c = _cos(grads[name], refg)
+        worst = min(worst, c)
+        assert c >= 0.995, (name, c)
+        checked += 1
+    print(f"12-layer KD step: {checked} parameter tensors, worst gradient cosine {worst:.5f}")
+    assert checked >= 150
+    # a second step after zero_grad(set_to_none=True) starts from a zeroed buffer again (no stale accumulation)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-5)
+    opt.zero_grad(set_to_none=True)
+    assert model.p(model.names[0]).grad is None
+    out2 = loss_fn(torch.einsum("th,tdh->td", model(q_ids, q_mask), model(d_ids, d_mask).view(tuples, docs, -1)),
+                   torch.from_numpy(teacher).cuda())
+    out2["loss"].backward()
+    for name in ("encoder.layer.11.output.dense.weight", "embeddings.word_embeddings.weight"):
+        assert _cos(model.p(name).grad.cpu().numpy(), grads[name]) > 0.9999, name
