@@ -489,30 +489,48 @@ int layer_backward(const Dims& d, const sskd_generic_layer_weights& lw, const ss
 //   logit = out_w . tanh(dense_w . h[<s>] + dense_b) + out_b
 // A reranker's product is an ordering of near-equal logits, and the head is 2 H^2 FLOPs per pair (0.002 % of the
 // encoder's work): there is nothing to gain from bf16 here, and the round-2 bf16 head (bf16 dense output, bf16
-// tanh, bf16 weights) added its own rounding on top of the encoder's.  Wave w computes dense rows w, w + 4, ...
-// (one coalesced fp32 row read per wave-instruction, the <s> state in LDS), then a fixed-order block reduction.
-__global__ __launch_bounds__(256) void teacher_head_kernel(const bf16_t* __restrict__ hidden, int S, int H,
-                                                           const float* __restrict__ dense_w, const float* __restrict__ dense_b,
-                                                           const float* __restrict__ out_w, const float* __restrict__ out_b,
-                                                           float* __restrict__ logits) {
-  __shared__ float xs[1024];
-  __shared__ float part[4];
+// tanh, bf16 weights) added its own rounding on top of the encoder's.  16 waves per workgroup; a wave computes dense
+// rows w, w + 16, ... FOUR at a time (16-byte loads of whole fp32 rows, the <s> state in LDS; the first version - 4
+// waves, one row and 4-byte loads at a time - was latency-bound at 1.4 ms per launch), then a fixed-order block
+// reduction, so a logit is bit-reproducible from run to run.
+constexpr int HEAD_WAVES = 16;
+__global__ __launch_bounds__(HEAD_WAVES * 64) void teacher_head_kernel(const bf16_t* __restrict__ hidden, int S, int H,
+                                                                      const float* __restrict__ dense_w,
+                                                                      const float* __restrict__ dense_b,
+                                                                      const float* __restrict__ out_w,
+                                                                      const float* __restrict__ out_b, float* __restrict__ logits) {
+  __shared__ __attribute__((aligned(16))) float xs[1024];
+  __shared__ float part[HEAD_WAVES];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bf16_t* h = hidden + (int64_t)b * S * H;   // token 0 of sequence b
-  for (int c = tid; c < H; c += 256) xs[c] = (float)h[c];
+  for (int c = tid; c < H; c += HEAD_WAVES * 64) xs[c] = (float)h[c];
   __syncthreads();
-  float acc = 0.f;   // this wave's share of sum_r out_w[r] tanh(...)
-  for (int r = wave; r < H; r += 4) {
-    const float* wr = dense_w + (int64_t)r * H;
-    float d = 0.f;
-    for (int c = lane; c < H; c += 64) d = fmaf(wr[c], xs[c], d);
+  float acc = 0.f;   // this wave's share of sum_r out_w[r] tanh(...), rows in increasing order
+  const int H4 = H / 4;   // H % 32 == 0
+  for (int r0 = 4 * wave; r0 < H; r0 += 4 * HEAD_WAVES) {
+    float d[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = lane; c < H4; c += 64) {
+      const float4 x = reinterpret_cast<const float4*>(xs)[c];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
-    acc = fmaf(out_w[r], tanhf(d + dense_b[r]), acc);   // identical in every lane of the wave
+      for (int u = 0; u < 4; ++u) {
+        const float4 w = reinterpret_cast<const float4*>(dense_w + (int64_t)(r0 + u) * H)[c];
+        d[u] = fmaf(w.x, x.x, fmaf(w.y, x.y, fmaf(w.z, x.z, fmaf(w.w, x.w, d[u]))));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) d[u] += __shfl_xor(d[u], o);
+      acc = fmaf(out_w[r0 + u], tanhf(d[u] + dense_b[r0 + u]), acc);   // identical in every lane of the wave
+    }
   }
   if (lane == 0) part[wave] = acc;
   __syncthreads();
-  if (tid == 0) logits[b] = ((part[0] + part[1]) + (part[2] + part[3])) + out_b[0];
+  if (tid == 0) {
+    float s = 0.f;
+    for (int w = 0; w < HEAD_WAVES; ++w) s += part[w];
+    logits[b] = s + out_b[0];
+  }
 }
 
 }  // namespace
@@ -617,7 +635,7 @@ int sskd_teacher_score(const sskd_generic_config* cfg, const sskd_generic_weight
   hipStream_t st = sskd::as_stream(stream);
   const bf16_t* fin = nullptr;
   TRY(forward_all(cfg, w, d, d_ids, d_mask, sv, st, &fin));
-  hipLaunchKernelGGL(teacher_head_kernel, dim3(B), dim3(256), 0, st, fin, S, d.H, d_head_dense_w, d_head_dense_b,
+  hipLaunchKernelGGL(teacher_head_kernel, dim3(B), dim3(HEAD_WAVES * 64), 0, st, fin, S, d.H, d_head_dense_w, d_head_dense_b,
                      d_head_out_w, d_head_out_b, d_logits);
   return sskd::check_launch("teacher_head_kernel");
 }

@@ -252,20 +252,33 @@ class TeacherModel:
         if Sp != S:
             ids = torch.nn.functional.pad(ids, (0, Sp - S), value=self.config.pad_token_id)
             mask = torch.nn.functional.pad(mask, (0, Sp - S))
-        ids, mask = ids.contiguous(), mask.contiguous()
         if out is None:
             out = torch.empty(B, dtype=torch.float32, device=self.torch_device)
         if B == 0:
             return out
-        need = int(lib.sskd_teacher_workspace_bytes(self._cfg, B, Sp))
+        # tokens per launch a multiple of 256 (8 rows x 32): the weight GEMMs then run on the 256-row tile kernel
+        # (1.0-1.2 PFLOP/s) instead of the 128-row fallback for ragged shapes; the filler rows repeat row 0 and
+        # their scores are dropped (a row's score does not depend on its batch-mates)
+        Bp = -(-B // 8) * 8
+        user_out = None
+        if Bp != B:
+            ids = torch.cat([ids, ids[:1].expand(Bp - B, -1)])
+            mask = torch.cat([mask, mask[:1].expand(Bp - B, -1)])
+            user_out, out = out, torch.empty(Bp, dtype=torch.float32, device=self.torch_device)
+        ids, mask = ids.contiguous(), mask.contiguous()
+        B_launch = Bp
+        need = int(lib.sskd_teacher_workspace_bytes(self._cfg, B_launch, Sp))
         if self._workspace is None or self._workspace.numel() < need:
             self._workspace = None
             self._workspace = torch.empty(need, dtype=torch.uint8, device=self.torch_device)
         with torch.cuda.device(self.torch_device):
             _native.check(lib.sskd_teacher_score(
-                self._cfg, self._w, *self._head, ids.data_ptr(), mask.data_ptr(), B, Sp, out.data_ptr(),
+                self._cfg, self._w, *self._head, ids.data_ptr(), mask.data_ptr(), B_launch, Sp, out.data_ptr(),
                 self._workspace.data_ptr(), self._workspace.numel(),
                 int(torch.cuda.current_stream(self.torch_device).cuda_stream)))
+        if user_out is not None:
+            user_out.copy_(out[:B])
+            return user_out
         return out
 
     def tokenize_pairs(self, pairs: Sequence[Union[Tuple[str, str], List[str]]]):
@@ -310,7 +323,7 @@ class TeacherModel:
             lo = 0
             while lo < m:
                 width = max(int(lengths[lo]), 1)
-                rows = max(1, budget // (-(-width // 32) * 32))
+                rows = max(8, budget // (-(-width // 32) * 32) // 8 * 8)   # whole 256-token multiples per launch
                 self.score_token_ids(ids[lo : lo + rows, :width], mask[lo : lo + rows, :width], out=sorted_out[lo : lo + rows])
                 lo += rows
             out[c0 + torch.from_numpy(order).to(self.torch_device)] = sorted_out   # one un-permute per chunk

@@ -204,7 +204,7 @@ def test_kd_training_step_matches_oracle_and_learns(gpu):
         if "key.bias" in name or np.linalg.norm(refg) < 1e-10:
             continue
         c = _cos(model.p(name).grad.cpu().numpy(), refg)
-        assert c >= 0.995, (name, c)
+        assert c >= 0.999, (name, c)   # the per-tensor gate of the encoder-only test holds for the whole step too
         checked += 1
     assert checked >= 30
     # optimisation: the same batch, a few AdamW steps
@@ -266,7 +266,7 @@ def test_kd_step_at_bench_depth_and_geometry_vs_oracle(gpu):
             continue
         c = _cos(grads[name], refg)
         worst = min(worst, c)
-        assert c >= 0.995, (name, c)
+        assert c >= 0.999, (name, c)   # measured worst 0.99954 over 185 tensors (gpurun_out/r03_prof: 12 layers)
         checked += 1
     print(f"12-layer KD step: {checked} parameter tensors, worst gradient cosine {worst:.5f}")
     assert checked >= 150
