@@ -245,8 +245,7 @@ class TeacherModel:
         """Raw logits fp32 ``[B]`` (device) for pre-tokenised pair sequences ``<s> q </s></s> d </s>``
         (right-padded with ``pad_token_id``).  Enqueued on the current stream."""
         lib = _native.load()
-        ids = torch.as_tensor(input_ids).to(device=self.torch_device, dtype=torch.int32)
-        mask = torch.as_tensor(attention_mask).to(device=self.torch_device, dtype=torch.int32)
+        ids, mask = self._to_device_i32(input_ids, attention_mask)
         B, S = ids.shape
         Sp = max(32, -(-S // 32) * 32)
         if Sp != S:
@@ -280,6 +279,19 @@ class TeacherModel:
             user_out.copy_(out[:B])
             return user_out
         return out
+
+    def _to_device_i32(self, input_ids, attention_mask):
+        """Host arrays travel as ONE pinned block with a non-blocking copy: a pageable ``.to(device)`` makes the host wait
+        for everything already enqueued, which serialised tokenising chunk c + 1 behind the GPU work of chunk c."""
+        if isinstance(input_ids, torch.Tensor) and isinstance(attention_mask, torch.Tensor):
+            return (input_ids.to(device=self.torch_device, dtype=torch.int32),
+                    attention_mask.to(device=self.torch_device, dtype=torch.int32))
+        a, m = np.asarray(input_ids), np.asarray(attention_mask)
+        stage = torch.empty((2,) + a.shape, dtype=torch.int32, pin_memory=True)
+        stage[0].copy_(torch.from_numpy(np.ascontiguousarray(a, np.int32)))
+        stage[1].copy_(torch.from_numpy(np.ascontiguousarray(m, np.int32)))
+        dev = stage.to(self.torch_device, non_blocking=True)
+        return dev[0], dev[1]
 
     def tokenize_pairs(self, pairs: Sequence[Union[Tuple[str, str], List[str]]]):
         if self.tokenizer is None:
@@ -326,7 +338,9 @@ class TeacherModel:
                 rows = max(8, budget // (-(-width // 32) * 32) // 8 * 8)   # whole 256-token multiples per launch
                 self.score_token_ids(ids[lo : lo + rows, :width], mask[lo : lo + rows, :width], out=sorted_out[lo : lo + rows])
                 lo += rows
-            out[c0 + torch.from_numpy(order).to(self.torch_device)] = sorted_out   # one un-permute per chunk
+            perm = torch.empty(m, dtype=torch.int64, pin_memory=True)
+            perm.copy_(torch.from_numpy(order.astype(np.int64) + c0))
+            out[perm.to(self.torch_device, non_blocking=True)] = sorted_out   # one un-permute per chunk
         return out
 
     def score(self, pairs: Sequence[Union[Tuple[str, str], List[str]]], batch_size: int = 32) -> List[float]:
