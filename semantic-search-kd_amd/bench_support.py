@@ -74,6 +74,8 @@ def bench_encode(device, world: int, steps: int, warmup: int, barrier, batch: in
         "ragged": bench_encode_ragged(enc, device) if ragged else None,
         # and end to end from Python strings (tokenise + H2D + forward + D2H) through StudentModel
         "text": bench_encode_text(enc, device) if text else None,
+        # cfg 3's per-rank build: text -> HBM index shard, embeddings never leave the device
+        "index_build": bench_index_build(enc, device) if text else None,
     }
 
 
@@ -181,6 +183,41 @@ def bench_encode_text(enc: Mi355xSentenceEncoder, device, n_docs: int = 32768, p
         "padding_overhead": round(stats["padding_overhead"], 4),
         "tokenizer_alone_docs_per_s": round(tok_rate, 1),
         "unit_norm_ok": bool(np.allclose(np.linalg.norm(emb, axis=1), 1.0, atol=1e-3)),
+    }
+
+
+def bench_index_build(enc: "Mi355xSentenceEncoder", device, n_docs: int = 131072):
+    """BASELINE cfg 3's build step as ONE rank runs it (scripts/build_faiss_index.py:45-72 per shard, sharded_index.
+    build_sharded): MS MARCO-shaped passages (Python str) -> tokenise -> packed encoder -> embeddings stay in HBM ->
+    ``FAISSIndexBuilder.add`` (normalise + tile) -> screening sidecar.  No host round trip of the embeddings.  A rank of
+    the 8-GPU job owns 1 105 228 passages: the projected shard build time is reported beside the measured rate."""
+    from .encoder import build_wordpiece_tokenizer
+    from .index import FAISSIndexBuilder
+    from .student import StudentModel
+
+    vocab = synthetic_vocab(enc.config.vocab_size)
+    if enc.tokenizer is None:
+        enc.tokenizer = build_wordpiece_tokenizer(vocab)
+    student = StudentModel.from_encoder(enc, "e5-small-v2-synthetic")
+    docs = synthetic_passages(vocab, n_docs, seed=31)
+    student.encode_documents_device(docs[:8192])      # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    index = FAISSIndexBuilder(embedding_dim=enc.config.hidden_size, index_type="HNSW", metric="cosine", device=str(device))
+    index.reserve(n_docs)
+    slab = 65536
+    for lo in range(0, n_docs, slab):
+        index.add(student.encode_documents_device(docs[lo : lo + slab]))
+    q = torch.nn.functional.normalize(torch.randn((64, enc.config.hidden_size), device=device), dim=1)
+    index.search_device(q, 10)                          # builds the bf16 screening sidecar
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(n_docs / dt, 1), "unit": "docs/s",
+        "workload": f"{n_docs} synthetic-vocabulary passages (str) -> embeddings -> HBM index shard + screening sidecar, on one GPU",
+        "seconds": round(dt, 3),
+        "projected_seconds_for_a_1105228_passage_shard": round(1105228 / (n_docs / dt), 1),
+        "ntotal": int(index.ntotal),
     }
 
 
