@@ -488,7 +488,11 @@ __global__ __launch_bounds__(512) void gemm_tn384_kernel(GemmTnArgs p) {
 //                    QUERY on the lane, so the online softmax is lane-local (+ one exchange with lane ^ 32)
 //   O^T = V^T P^T    B = P^T: the score accumulators, exponentiated and packed, ARE the B operand
 //                    (k index 8h + e' <-> key 16 s2 + 8 (e' >> 2) + 4h + (e' & 3)); A = V^T fragments
-//                    [dim, key] in that same key order - V is transposed into it while being staged.
+//                    [dim, key] in that same key order.  V is staged ROW-MAJOR ([key][dim], 16-byte stores) and
+//                    transposed by the READ: ds_read_b64_tr_b16 hands a lane one dim column of four key rows,
+//                    and the four rows are whatever the lanes' addresses say - here keys base + 0..3 of the packed
+//                    order, two reads per fragment.  (Rounds 1-2 transposed while staging, with 8 two-byte LDS
+//                    stores per 16 bytes loaded: 8-way bank conflicts, about a third of the kernel.)
 // Same operand trick as the hidden-384 inference kernel (encoder.hip), with operands from memory.
 // ------------------------------------------------------------------------- //
 constexpr float ATT_NEG = -1.0e30f;
@@ -506,6 +510,37 @@ struct AttnArgs {
 
 __device__ inline float pair_max32(float v) { return fmaxf(v, __shfl_xor(v, 32)); }
 __device__ inline float pair_sum32(float v) { return v + __shfl_xor(v, 32); }
+
+// Row-major [key][DH] bf16 image of a head's V in LDS, read TRANSPOSED.  Byte offset of 16-byte chunk c of key k:
+// k * 2 DH + (16 c ^ att_vswz(k)).  The XOR moves whole 64-byte groups of a row so that the four key rows of one
+// transposing read (consecutive keys, same dims) fall into different banks: rows are 64 / 128 / 256 bytes for head
+// widths 32 / 64 / 128 and a ds_read_b64_tr_b16 half-wave reads 64 contiguous bytes of each of its 4 rows (bank =
+// (address / 4) % 64): at 64-byte rows the four rows already tile the 64 banks; at 128 bytes rows k and k + 2 collide
+// (swap the row's two 64-byte halves when bit 1 of k is set); at 256 bytes all four collide (rotate by k & 3).
+template <int DH>
+__device__ inline int att_vswz(int key) {
+  return DH == 128 ? (key & 3) << 6 : DH == 64 ? ((key >> 1) & 1) << 6 : 0;
+}
+
+// A-operand fragment of O^T = V^T P^T for key tile kt, dim tile t, 16-key half s2: lane l holds V[key][dim 32 t + (l & 31)]
+// for the 8 keys 32 kt + 16 s2 + 8 (e' >> 2) + 4 (l >> 5) + (e' & 3), e' = 0 .. 7 - two transposing reads of 4 keys each.
+// Lane 4 q + pidx of a 16-lane group supplies the address of key row q, dims 4 pidx .. + 3 of the group's 16 dims.
+// EXEC must be all ones (whole waves only call this).
+template <int DH>
+__device__ inline bf16x8 att_vt_frag(const bf16_t* vl, int kt, int t, int s2, int lane) {
+  const int grp = lane >> 4, q = (lane & 15) >> 2, pidx = lane & 3, h = lane >> 5;
+  const int dim0 = 32 * t + 16 * (grp & 1) + 4 * pidx;       // first of this lane's 4 address dims
+  const unsigned char* base = reinterpret_cast<const unsigned char*>(vl);
+  s16x8 out;
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    const int key = 32 * kt + 16 * s2 + 8 * which + 4 * h + q;
+    const int off = key * (DH * 2) + (((dim0 >> 3) << 4) ^ att_vswz<DH>(key)) + 2 * (dim0 & 7);
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off));
+    out[4 * which + 0] = v[0]; out[4 * which + 1] = v[1]; out[4 * which + 2] = v[2]; out[4 * which + 3] = v[3];
+  }
+  return __builtin_bit_cast(bf16x8, out);
+}
 
 template <int DH>
 __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnArgs p) {
@@ -539,15 +574,9 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnArgs p) {
     const int key = v / CPK, c = v - key * CPK;
     const bf16x8 kv = *reinterpret_cast<const bf16x8*>(base + (int64_t)key * ld + p.H + 8 * c);
     kl[((key >> 5) * KS + (c >> 1)) * 64 + (key & 31) + 32 * (c & 1)] = kv;
-    // V: the same piece of the V block, scattered transposed into the P^T key order
+    // V: the same piece of the V block, row-major [key][dim] (swizzled against the transposing reads' bank conflicts)
     const bf16x8 vv = *reinterpret_cast<const bf16x8*>(base + (int64_t)key * ld + 2 * p.H + 8 * c);
-    const int kk = key & 31, g = kk >> 3, hh = (kk >> 2) & 1, e = kk & 3;
-    const int s2 = g >> 1, ep = 4 * (g & 1) + e;
-#pragma unroll
-    for (int e8 = 0; e8 < 8; ++e8) {
-      const int d = 8 * c + e8;
-      vl[(((((key >> 5) * DT + (d >> 5)) * 2 + s2) * 64) + (d & 31) + 32 * hh) * 8 + ep] = vv[e8];
-    }
+    *reinterpret_cast<bf16x8*>(reinterpret_cast<unsigned char*>(vl) + key * (DH * 2) + ((16 * c) ^ att_vswz<DH>(key))) = vv;
   }
   const int qt = qs * 8 + wave;
   const bool active = qt < p.nkt;
@@ -567,7 +596,6 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnArgs p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
   float m = ATT_NEG, l = 0.f;
-  const bf16x8* vfr = reinterpret_cast<const bf16x8*>(vl);
   for (int kt = 0; kt < kmax; ++kt) {
     f32x16 sc;
 #pragma unroll
@@ -607,8 +635,8 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnArgs p) {
     l += ps;
 #pragma unroll
     for (int t = 0; t < DT; ++t) {
-      o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[((kt * DT + t) * 2 + 0) * 64 + lane], pf[0], o[t], 0, 0, 0);
-      o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[((kt * DT + t) * 2 + 1) * 64 + lane], pf[1], o[t], 0, 0, 0);
+      o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_vt_frag<DH>(vl, kt, t, 0, lane), pf[0], o[t], 0, 0, 0);
+      o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_vt_frag<DH>(vl, kt, t, 1, lane), pf[1], o[t], 0, 0, 0);
     }
   }
   l = pair_sum32(l);
