@@ -52,4 +52,9 @@ for M, N, K, f32, acc, label in SHAPES:
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
         line += f" | {name}: {ms * 1e3:8.1f} us {2.0 * M * N * K / ms / 1e9:7.1f} TF/s"
+        if not acc and M * N <= 1 << 28:   # sampled rows against torch in fp32 (the probe doubles as a smoke check of a variant)
+            rows = torch.randint(0, M, (512,), device=dev)
+            ref = a[rows].float() @ b.float().T
+            err = ((c[rows].float() - ref).abs().max() / ref.abs().max()).item()
+            line += f" err {err:.1e}" + ("" if err < 1.5e-2 else " MISMATCH")
     print(line, flush=True)
