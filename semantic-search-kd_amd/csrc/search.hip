@@ -44,6 +44,11 @@ __device__ inline float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+__device__ inline int wave_sum_int(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
 
 // One workgroup per tile. Rows go global(row-major) -> LDS -> global(tiled).
 __global__ __launch_bounds__(256) void index_add_rows_kernel(
@@ -742,32 +747,29 @@ __global__ __launch_bounds__(64) void similarity_kernel(const float* __restrict_
 // With e bounding |screen score - exact fp32 score|, every row of the
 // exact top k has a screen score >= (k-th best screen score) - 2e: those rows are the candidates.
 // They are re-scored with the exact k-ordered fma chain of the fp32 MFMA, so the final scores and
-// ids are bit-identical to the exact scan's.  The per-lane lists can truncate the candidate set
-// only where a list is FULL with its last entry still inside the candidate band; that is detected
-// per query, and such queries (duplicate-heavy neighbourhoods) are answered by the exact scan in
-// a fallback launch sized for EVERY query of the call - results are never approximate and no
-// entry point can return an unproven row.
+// ids are bit-identical to the exact scan's.  Every row whose screen score reaches the pruning bound
+// (a lower bound of the k-th best screen score, minus 2e) is APPENDED to a per-lane run in global memory,
+// so the appended set always contains the whole candidate band; a query is handed to the exact scan only
+// when a run overflowed, its entries do not fit the finalize kernel's LDS stage, or its band holds more
+// than SCREEN_MAX_CAND rows (hundreds of near-duplicates of its neighbours) - in a fallback launch sized
+// for EVERY query of the call: results are never approximate and no entry point can return an unproven row.
 // ------------------------------------------------------------------------- //
 typedef __bf16 sbf16x8 __attribute__((ext_vector_type(8)));
 constexpr int BSTEPS = DIM / 16;                 // 24 k-steps of the 32x32x16 bf16 MFMA
 constexpr int BTILE_VEC = BSTEPS * 64;           // 16-byte vectors per 32-row bf16 tile (24 KiB)
 #ifndef SSKD_SCREEN_BGROUP
-#define SSKD_SCREEN_BGROUP 4
+#define SSKD_SCREEN_BGROUP 6
 #endif
 #ifndef SSKD_SCREEN_WAVES
-#define SSKD_SCREEN_WAVES 8
+#define SSKD_SCREEN_WAVES 12
 #endif
 #ifndef SSKD_SCREEN_RING
-#define SSKD_SCREEN_RING 3
-#endif
-#ifndef SSKD_SCREEN_LISTK
-#define SSKD_SCREEN_LISTK 6
+#define SSKD_SCREEN_RING 2
 #endif
 constexpr int BGROUP = SSKD_SCREEN_BGROUP;       // k-steps per prefetch group
 constexpr int BGROUPS = BSTEPS / BGROUP;
 constexpr int SCREEN_WAVES = SSKD_SCREEN_WAVES;  // waves per screening workgroup
 constexpr int SCREEN_RING = SSKD_SCREEN_RING;    // register buffers of one group each; RING - 1 groups are in flight
-constexpr int SCREEN_LISTK = SSKD_SCREEN_LISTK;  // depth of the per-lane lists (the pools keep 10 slots regardless)
 static_assert(BSTEPS % BGROUP == 0 && BGROUPS % SCREEN_RING == 0 && SCREEN_RING >= 2, "screening prefetch geometry");
 // fp32 accumulation slack of the two dot products, relative to |q| max|c|: the exact score is a 384-step fma
 // chain (<= 384 x 2^-24), the screen score 24 MFMAs of 16 exact products each accumulated in fp32 (<= 2 x 384
@@ -779,7 +781,6 @@ constexpr int SCREEN_MAX_CAND = 256;             // candidates re-scored per que
 // the usual case - still fills the chip), the rest to a launch planned for nq - TIER1 (only duplicate-flooded corpora
 // ever get there).  Both read their actual query count from device memory; with none, every workgroup exits at once.
 constexpr int SCREEN_FALLBACK_TIER1 = 1024;
-constexpr int SCREEN_MAX_ENTRIES = 4096;         // list entries of one query staged in LDS
 constexpr int SCREEN_CUS = 256;                  // MI355X: the launch geometry is planned in whole rounds of the chip
 
 // fp32 tiled corpus -> bf16 tiled corpus in A-operand order of v_mfma_f32_32x32x16_bf16:
@@ -891,22 +892,6 @@ __global__ __launch_bounds__(256) void screen_eps_kernel(const float* __restrict
   }
 }
 
-struct ScreenParams {
-  const sbf16x8* tiled;     // bf16 tiles
-  const float* queries;     // fp32 [nq][384] (rounded to bf16 while staging)
-  const float* eps2;        // [nq]
-  float* part_scores;       // [nq][lists_per_query][K] screen scores
-  int* part_ids;
-  int* tau;
-  int* gpool;
-  int64_t n_rows;
-  int n_tiles;
-  int nq;
-  int n_slices;
-  int tiles_per_slice;
-  int lists_per_query;
-};
-
 __device__ inline void load_bgroup(sbf16x8 (&buf)[BGROUP], const sbf16x8* __restrict__ base) {
 #pragma unroll
   for (int s = 0; s < BGROUP; ++s) buf[s] = base[s * 64];
@@ -949,21 +934,80 @@ __device__ inline void screen_tile_groups(sbf16x8 (&buf)[SCREEN_RING][BGROUP], c
   }
 }
 
-// Same structure as scan_topk_kernel (query block in LDS, per-lane sorted lists, shared pruning
-// pools) on bf16 operands; the pools prune 2e BELOW the shared bound so that the whole candidate
-// band survives.
-template <int K, int QB, int WAVES, int LK = SCREEN_LISTK>
-__global__ __launch_bounds__(WAVES * 64) void screen_topk_kernel(ScreenParams p) {
+// wave-wide arg-best in rank order (higher score, then lower id); i < 0 = nothing
+__device__ inline void wave_argbest(float& s, int& i) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float os = __shfl_xor(s, o);
+    const int oi = __shfl_xor(i, o);
+    if (oi >= 0 && (i < 0 || ranks_before(os, oi, s, i))) { s = os; i = oi; }
+  }
+}
+
+// ------------------------------------------------------------------------- //
+// The screening kernel.  Structure of scan_topk_kernel (query block of 128 in LDS as B fragments, every wave streams
+// its own corpus tiles through a register ring, shared pruning pools) on bf16 operands, with one difference: no
+// per-lane sorted lists.  A lane APPENDS every row that reaches the pruning bound - score >= (best known lower bound
+// of the query's k-th best screen score) - 2e - to a private run of SCREEN_CAP entries in global memory (8-byte
+// fire-and-forget stores, no atomics; the count lives in a register).  Every bound is a valid lower bound of the
+// final k-th best screen score, so the appended set always contains the whole candidate band {score >= kth - 2e}:
+// nothing to prove afterwards except that no run overflowed.  (Rounds 2-3 kept 6- or 8-deep sorted lists in
+// registers: 12 registers per 32-query sub-block, an insertion network per accepted row, and a "list full inside the
+// band" failure mode that sent near-duplicate neighbourhoods to the exact scan.)  Without the lists the kernel fits
+// THREE waves per SIMD (12 waves per workgroup, 168 registers): 8.6 -> 7.8 ms at the bench shape, 1.66 -> 1.30 ms on
+// the 125 k-row shard of an 8-GPU split.
+// A PRE-PASS (BOUND_ONLY = true) runs the same kernel over the first SCREEN_PRE_TILES x 32 rows and only publishes
+// its bounds (tau + the global buckets): the main pass then starts from the k-th best of that sample instead of
+// -inf, which cuts the appended entries per query from ~1 400 (every slice starts cold: its first tiles pass whole)
+// to a few hundred.
+// ------------------------------------------------------------------------- //
+#ifndef SSKD_SCREEN_CAP
+#define SSKD_SCREEN_CAP 64
+#endif
+#ifndef SSKD_SCREEN_FIN_ENTRIES
+#define SSKD_SCREEN_FIN_ENTRIES 1024
+#endif
+constexpr int SCREEN_CAP = SSKD_SCREEN_CAP;   // entries per (query, wave, half-wave) run
+#ifndef SSKD_SCREEN_PRE_TILES
+#define SSKD_SCREEN_PRE_TILES 64
+#endif
+constexpr int SCREEN_PRE_TILES = SSKD_SCREEN_PRE_TILES;   // rows / 32 of the bound-only pre-pass
+constexpr int SCREEN_FIN_ENTRIES = SSKD_SCREEN_FIN_ENTRIES;   // appended entries of one query staged in LDS by the finalize kernel
+
+struct ScreenAppendParams {
+  const sbf16x8* tiled;     // bf16 tiles
+  const float* queries;     // fp32 [nq][384] (rounded to bf16 while staging)
+  const float* eps2;        // [nq]
+  uint2* cand;              // [nq][lists_per_query][SCREEN_CAP]: (score bits, row id)
+  int* cand_cnt;            // [nq][lists_per_query]: rows that reached the bound (> SCREEN_CAP: the run overflowed)
+  int* tau;
+  int* gpool;
+  int64_t n_rows;
+  int n_tiles;              // tiles this launch covers (the pre-pass: the sample)
+  int nq;
+  int n_slices;
+  int tiles_per_slice;
+  int lists_per_query;
+};
+
+// out of line: the cold path must not cost the screening loop registers
+__device__ __attribute__((noinline)) int screen_compact_run(unsigned long long* run, int n, float thr) {
+  int w = 0;
+  for (int i = 0; i < n; ++i) {
+    const unsigned long long e = __hip_atomic_load(run + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__uint_as_float((unsigned)e) >= thr) run[w++] = e;
+  }
+  return w;
+}
+
+template <int K, int QB, int WAVES, bool BOUND_ONLY>
+__global__ __launch_bounds__(WAVES * 64) void screen_append_kernel(ScreenAppendParams p) {
   extern __shared__ float4 qs_raw[];
   sbf16x8* const qs = reinterpret_cast<sbf16x8*>(qs_raw);  // [QB][24 steps][64 lanes]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, h = lane >> 5;
-#ifdef SSKD_SCREEN_NO_XCD_MAP
-  const int slice = blockIdx.x % p.n_slices;
-  const int qblk = blockIdx.x / p.n_slices;
-#else
   // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8) and each XCD has its own L2: give XCD x
   // a CONTIGUOUS range of (slice, query block) pairs, slice-major, so that a slice's tiles are pulled
   // through one or two L2s instead of all eight.
@@ -972,7 +1016,6 @@ __global__ __launch_bounds__(WAVES * 64) void screen_topk_kernel(ScreenParams p)
   const int logical = xcd * (gridDim.x >> 3) + min(xcd, (int)(gridDim.x & 7)) + within;
   const int slice = logical / n_qblocks;
   const int qblk = logical % n_qblocks;
-#endif
   const int q0 = qblk * (32 * QB);
 
   for (int idx = tid; idx < QB * BSTEPS * 64; idx += WAVES * 64) {
@@ -995,20 +1038,22 @@ __global__ __launch_bounds__(WAVES * 64) void screen_topk_kernel(ScreenParams p)
   __syncthreads();
   const sbf16x8* qlane = qs + lane;
 
-  LaneList<LK> list[QB];
   float gthr[QB];   // best known lower bound on the query's final K-th SCREEN score, minus 2e
   float band[QB];
-  int* tau_q[QB];
+  int cnt[QB];
   bool real[QB];
 #pragma unroll
   for (int qq = 0; qq < QB; ++qq) {
-    gthr[qq] = -INFINITY;
+    gthr[qq] = -FLT_MAX;   // finite: the -inf scores of rows past n_rows never pass
     const int qg = q0 + qq * 32 + j;
     real[qq] = qg < p.nq;
-    tau_q[qq] = p.tau + (real[qq] ? qg : p.nq - 1);
     band[qq] = p.eps2[real[qq] ? qg : p.nq - 1];
-    list[qq].clear();
+    cnt[qq] = 0;
   }
+  // run of (query q0 + j, this wave, this half-wave); sub-block qq is 32 queries further
+  const int my_list = (slice * WAVES + wave) * 2 + h;
+  uint2* const run0 = p.cand + ((int64_t)min(q0 + j, p.nq - 1) * p.lists_per_query + my_list) * SCREEN_CAP;
+  const int64_t run_stride = (int64_t)32 * p.lists_per_query * SCREEN_CAP;
 
   const int t_begin = slice * p.tiles_per_slice;
   const int t_end = min(t_begin + p.tiles_per_slice, p.n_tiles);
@@ -1037,7 +1082,7 @@ __global__ __launch_bounds__(WAVES * 64) void screen_topk_kernel(ScreenParams p)
 #pragma unroll
         for (int i = 1; i < K; ++i)
           bmin = min(bmin, __hip_atomic_load(&gb[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        const int old = atomicMax(tau_q[qq], max(w, bmin));
+        const int old = atomicMax(p.tau + q0 + qq * 32 + j, max(w, bmin));
         gthr[qq] = fmaxf(gthr[qq], ordered_to_float(max(old, bmin)) - band[qq]);
       }
     }
@@ -1050,14 +1095,14 @@ __global__ __launch_bounds__(WAVES * 64) void screen_topk_kernel(ScreenParams p)
     screen_tile_groups<QB, 0>(buf, tile, qlane, acc, t + WAVES < t_end, (int64_t)WAVES * BTILE_VEC);
 
     const int rowbase = t * TILE_ROWS + 4 * h;
-    if (ragged && t == p.n_tiles - 1) {
+    if (ragged && (int64_t)(t + 1) * TILE_ROWS > p.n_rows) {
 #pragma unroll
       for (int qq = 0; qq < QB; ++qq)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (rowbase + (r & 3) + 8 * (r >> 2) >= p.n_rows) acc[qq][r] = -INFINITY;
     }
-#ifdef SSKD_SCREEN_ABL_NOLIST  // timing ablation: no list / pool maintenance (accumulators kept alive)
+#ifdef SSKD_SCREEN_ABL_NOLIST  // timing ablation: no candidate / pool maintenance (accumulators kept alive)
 #pragma unroll
     for (int qq = 0; qq < QB; ++qq)
 #pragma unroll
@@ -1069,16 +1114,34 @@ __global__ __launch_bounds__(WAVES * 64) void screen_topk_kernel(ScreenParams p)
       float m = acc[qq][0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[qq][r]);
-      if (__any(m > list[qq].s[LK - 1] && m >= gthr[qq])) {
+      if (__any(real[qq] && m >= gthr[qq])) {
+#ifndef SSKD_SCREEN_NO_COMPACT
+        if constexpr (!BOUND_ONLY) {
+          // A run that could fill up inside this tile (16 rows) first drops what the bound has overtaken since it was
+          // appended: rows arriving in ascending order of their score - a corpus sorted by topic - pass the bound one
+          // after the other and the bound follows them, so the entries worth keeping are the band of the CURRENT
+          // bound.  Own stores, read back from L2 after they were acknowledged; forward in-place compaction (w <= i).
+          const bool tight = cnt[qq] > SCREEN_CAP - 16 && cnt[qq] <= SCREEN_CAP;
+          if (__any(tight)) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            if (tight) cnt[qq] = screen_compact_run(reinterpret_cast<unsigned long long*>(run0 + qq * run_stride), cnt[qq], gthr[qq]);
+          }
+        }
+#endif
         bool grew = false;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float x = acc[qq][r];
           const int xid = rowbase + (r & 3) + 8 * (r >> 2);
-          const bool take = x > list[qq].s[LK - 1] && x >= gthr[qq];
+          const bool take = real[qq] && x >= gthr[qq];   // (padding queries own no run)
           if (__any(take)) {
             if (take) {
-              list[qq].insert(x, xid);
+              if constexpr (!BOUND_ONLY) {
+                unsigned long long* const run = reinterpret_cast<unsigned long long*>(run0 + qq * run_stride);
+                if (cnt[qq] < SCREEN_CAP)
+                  run[cnt[qq]] = (unsigned long long)__float_as_uint(x) | ((unsigned long long)(unsigned)xid << 32);
+                ++cnt[qq];   // (> SCREEN_CAP: the run overflowed - the band itself holds more than a run: exact fallback)
+              }
               if (tiles_done > 0) {
                 const int xi = float_to_ordered(x);
                 if (pool_offer<K>(pool + (qq * 32 + j) * K, wthr + qq * 32 + j, xi) && real[qq])
@@ -1090,8 +1153,8 @@ __global__ __launch_bounds__(WAVES * 64) void screen_topk_kernel(ScreenParams p)
           }
         }
         if (grew) {
-          if (tiles_done == 0)
-            pool_offer<K>(pool + (qq * 32 + j) * K, wthr + qq * 32 + j, float_to_ordered(list[qq].s[0]));
+          // first tile: every workgroup starts at the same instant - offer only the lane's best row
+          if (tiles_done == 0) pool_offer<K>(pool + (qq * 32 + j) * K, wthr + qq * 32 + j, float_to_ordered(m));
           gthr[qq] = fmaxf(gthr[qq], ordered_to_float(wthr[qq * 32 + j]) - band[qq]);
         }
       }
@@ -1102,23 +1165,22 @@ __global__ __launch_bounds__(WAVES * 64) void screen_topk_kernel(ScreenParams p)
   for (int qq = 0; qq < QB; ++qq) {
     const int q = q0 + qq * 32 + j;
     if (q < p.nq) {
-      const int64_t base = ((int64_t)q * p.lists_per_query + (slice * WAVES + wave) * 2 + h) * LK;
-#pragma unroll
-      for (int i = 0; i < LK; ++i) {
-        p.part_scores[base + i] = list[qq].s[i];
-        p.part_ids[base + i] = list[qq].id[i];
+      if constexpr (BOUND_ONLY) {
+        if (h == 0) atomicMax(p.tau + q, wthr[qq * 32 + j]);   // what this workgroup learned from its share of the sample
+      } else {
+        p.cand_cnt[(int64_t)q * p.lists_per_query + my_list] = cnt[qq];
       }
     }
   }
 }
 
-struct ScreenFinalParams {
-  const float* part_scores;   // [nq][lists][K] screen scores (sorted lists, (-inf, -1) padded)
-  const int* part_ids;
+struct ScreenFinalAppendParams {
+  const uint2* cand;          // [nq][lists][SCREEN_CAP]
+  const int* cand_cnt;        // [nq][lists]
   const float* eps2;
   const float* rows;          // fp32 rows, row-major (the sidecar's copy): exact re-scoring
   const float* queries;
-  int K, lists, k, nq;
+  int lists, k, nq;
   int64_t id_offset;
   float* out_scores;          // [nq][k]
   int64_t* out_ids;
@@ -1127,78 +1189,156 @@ struct ScreenFinalParams {
   float* fb_queries;          // [nq][384]
 };
 
-// wave-wide arg-best in rank order (higher score, then lower id); i < 0 = nothing
-__device__ inline void wave_argbest(float& s, int& i) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float os = __shfl_xor(s, o);
-    const int oi = __shfl_xor(i, o);
-    if (oi >= 0 && (i < 0 || ranks_before(os, oi, s, i))) { s = os; i = oi; }
-  }
-}
-
-// One WAVE per query (no workgroup barriers; 12 KiB of LDS at the bench shape, so a dozen queries
-// per CU are in flight): k-th best screen score -> candidate band -> proof that no list truncated
-// the band -> exact re-scoring (the fp32 MFMA's k-ordered fma chain) -> exact top k.
-// Dynamic LDS: [L] scores, [L] ids, [384] query, [SCREEN_MAX_CAND] candidate rows.
-__global__ __launch_bounds__(64) void screen_finalize_kernel(ScreenFinalParams p) {
+// One WAVE per query: gather the appended runs -> k-th best screen score -> candidate band -> exact re-scoring (the
+// fp32 MFMA's k-ordered fma chain) -> exact top k.  A query goes to the exact fallback when a run overflowed, when its
+// entries do not fit the LDS stage, or when the band holds more than SCREEN_MAX_CAND rows.
+// Dynamic LDS: [E] scores, [E] ids (E = SCREEN_FIN_ENTRIES), [384] query, [SCREEN_MAX_CAND] candidate rows.
+__global__ __launch_bounds__(64) void screen_finalize_append_kernel(ScreenFinalAppendParams p) {
   extern __shared__ __attribute__((aligned(16))) float fin_lds[];
-  const int L = p.lists * p.K;
   float* const es = fin_lds;
-  int* const ei = reinterpret_cast<int*>(fin_lds + L);
-  float* const qv = fin_lds + 2 * L;
+  int* const ei = reinterpret_cast<int*>(fin_lds + SCREEN_FIN_ENTRIES);
+  float* const qv = fin_lds + 2 * SCREEN_FIN_ENTRIES;
   int* const ci = reinterpret_cast<int*>(qv + DIM);
   const int q = blockIdx.x, lane = threadIdx.x;
-  const int64_t base = (int64_t)q * L;
-  for (int e = lane; e < L; e += 64) {
-    es[e] = p.part_scores[base + e];
-    ei[e] = p.part_ids[base + e];
-  }
   for (int c = lane; c < DIM; c += 64) qv[c] = p.queries[(int64_t)q * DIM + c];
-  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): one wave, its own LDS writes
 
-  // k-th best screen entry in rank order (k rounds of bounded arg-best)
-  float bs = INFINITY;
-  int bi = -1;
-  bool have = false;
-  float kth = -INFINITY;
-  int found = 0;
-  for (int r = 0; r < p.k; ++r) {
-    float s = -INFINITY;
-    int i = -1;
-    for (int e = lane; e < L; e += 64) {
-      const int id = ei[e];
-      if (id < 0) continue;
-      const float v = es[e];
-      if (have && !ranks_before(bs, bi, v, id)) continue;
-      if (i < 0 || ranks_before(v, id, s, i)) { s = v; i = id; }
-    }
-    wave_argbest(s, i);
-    if (i < 0) break;
-    bs = s; bi = i; have = true;
-    kth = s;
-    ++found;
-  }
-  // fewer than k rows exist at all: every entry is a candidate
-  const float tau = found == p.k ? kth - p.eps2[q] : -INFINITY;
-
-  // proof: a FULL list whose last entry is still inside the band may have dropped candidates
   bool bad = false;
-  for (int l = lane; l < p.lists; l += 64) {
-    const int e = l * p.K + p.K - 1;
-    if (ei[e] >= 0 && es[e] >= tau) bad = true;
+  int total = 0;
+  for (int l0 = 0; l0 < p.lists; l0 += 64) {
+    const int l = l0 + lane;
+    const int c = l < p.lists ? p.cand_cnt[(int64_t)q * p.lists + l] : 0;
+    if (c > SCREEN_CAP) bad = true;
+    total += wave_sum_int(min(c, SCREEN_CAP));
   }
-  // candidates, compacted in entry order (ballot prefix)
   int M = 0;
-  for (int e0 = 0; e0 < L; e0 += 64) {
-    const int e = e0 + lane;
-    const bool in = e < L && ei[e] >= 0 && es[e] >= tau;
-    const unsigned long long mask = __ballot(in);
-    if (in) {
-      const int slot = M + __popcll(mask & ((1ull << lane) - 1ull));
-      if (slot < SCREEN_MAX_CAND) ci[slot] = ei[e];
+  float tau;
+  if (total <= SCREEN_FIN_ENTRIES) {
+    // ---- the usual case: every entry staged in LDS ----
+    int base = 0;
+    for (int l0 = 0; l0 < p.lists; l0 += 64) {
+      const int l = l0 + lane;
+      const int c = l < p.lists ? min(p.cand_cnt[(int64_t)q * p.lists + l], SCREEN_CAP) : 0;
+      int incl = c;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+      }
+      const int off = base + incl - c;
+      const uint2* src = p.cand + ((int64_t)q * p.lists + l) * SCREEN_CAP;
+      for (int i = 0; i < c; ++i) {
+        const uint2 e = src[i];
+        es[off + i] = __uint_as_float(e.x);
+        ei[off + i] = (int)e.y;
+      }
+      base += __shfl(incl, 63);
     }
-    M += __popcll(mask);
+    const int L = total;
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): one wave, its own LDS writes
+
+    // k-th best screen entry in rank order (k rounds of bounded arg-best)
+    float bs = INFINITY;
+    int bi = -1;
+    bool have = false;
+    float kth = -INFINITY;
+    int found = 0;
+    for (int r = 0; r < p.k; ++r) {
+      float s = -INFINITY;
+      int i = -1;
+      for (int e = lane; e < L; e += 64) {
+        const int id = ei[e];
+        const float v = es[e];
+        if (have && !ranks_before(bs, bi, v, id)) continue;
+        if (i < 0 || ranks_before(v, id, s, i)) { s = v; i = id; }
+      }
+      wave_argbest(s, i);
+      if (i < 0) break;
+      bs = s; bi = i; have = true;
+      kth = s;
+      ++found;
+    }
+    // fewer than k rows exist at all: every entry is a candidate
+    tau = found == p.k ? kth - p.eps2[q] : -INFINITY;
+
+    // candidates, compacted in entry order (ballot prefix)
+    for (int e0 = 0; e0 < L; e0 += 64) {
+      const int e = e0 + lane;
+      const bool in = e < L && es[e] >= tau;
+      const unsigned long long mask = __ballot(in);
+      if (in) {
+        const int slot = M + __popcll(mask & ((1ull << lane) - 1ull));
+        if (slot < SCREEN_MAX_CAND) ci[slot] = ei[e];
+      }
+      M += __popcll(mask);
+    }
+  } else {
+    // ---- more entries than the stage holds (a shard too small for its bounds to warm up, or rows that arrive in
+    // ascending order of their score): stream the runs twice.  Pass 1: each lane keeps the k best SCORES of its runs
+    // (the k-th best score of the union is the k-th best of the union of those); pass 2 collects the band.
+    float top[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) top[i] = -INFINITY;
+    for (int l = lane; l < p.lists; l += 64) {
+      const int c = min(p.cand_cnt[(int64_t)q * p.lists + l], SCREEN_CAP);
+      const uint2* src = p.cand + ((int64_t)q * p.lists + l) * SCREEN_CAP;
+      for (int i = 0; i < c; ++i) {
+        float v = __uint_as_float(src[i].x);
+        if (v > top[9]) {
+          top[9] = v;
+#pragma unroll
+          for (int u = 9; u > 0; --u) {
+            const float a = top[u - 1], b = top[u];
+            top[u - 1] = fmaxf(a, b);
+            top[u] = fminf(a, b);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      es[lane * 10 + i] = top[i];
+      ei[lane * 10 + i] = top[i] > -INFINITY ? lane * 10 + i : -1;   // slot number as the id: a multiset selection
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    float bs = INFINITY;
+    int bi = -1;
+    bool have = false;
+    float kth = -INFINITY;
+    int found = 0;
+    for (int r = 0; r < p.k; ++r) {
+      float s = -INFINITY;
+      int i = -1;
+      for (int e = lane; e < 640; e += 64) {
+        const int id = ei[e];
+        if (id < 0) continue;
+        const float v = es[e];
+        if (have && !ranks_before(bs, bi, v, id)) continue;
+        if (i < 0 || ranks_before(v, id, s, i)) { s = v; i = id; }
+      }
+      wave_argbest(s, i);
+      if (i < 0) break;
+      bs = s; bi = i; have = true;
+      kth = s;
+      ++found;
+    }
+    tau = found == p.k ? kth - p.eps2[q] : -INFINITY;
+    int* const mcount = ei;   // the selection is done with ei
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    if (lane == 0) mcount[0] = 0;
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    for (int l = lane; l < p.lists; l += 64) {
+      const int c = min(p.cand_cnt[(int64_t)q * p.lists + l], SCREEN_CAP);
+      const uint2* src = p.cand + ((int64_t)q * p.lists + l) * SCREEN_CAP;
+      for (int i = 0; i < c; ++i) {
+        const uint2 e = src[i];
+        if (__uint_as_float(e.x) >= tau) {
+          const int slot = atomicAdd(mcount, 1);
+          if (slot < SCREEN_MAX_CAND) ci[slot] = (int)e.y;
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    M = mcount[0];
   }
   if (M > SCREEN_MAX_CAND) bad = true;
   if (__any(bad)) {
@@ -1214,7 +1354,6 @@ __global__ __launch_bounds__(64) void screen_finalize_kernel(ScreenFinalParams p
   __builtin_amdgcn_s_waitcnt(0xC07F);
 
   // exact scores, 64 candidates per round: the fma order of the 32x32x2 f32 MFMA chain (section 3.1).
-  // Each lane keeps the best (up to 4) of its own candidates; M <= 256.
   float cs[SCREEN_MAX_CAND / 64];
   int cid[SCREEN_MAX_CAND / 64];
 #pragma unroll
@@ -1239,7 +1378,9 @@ __global__ __launch_bounds__(64) void screen_finalize_kernel(ScreenFinalParams p
       cid[c] = (acc == acc) ? row : -1;  // a NaN score is never selected (as in the exact scan)
     }
   }
-  bs = INFINITY; bi = -1; have = false;
+  float bs = INFINITY;
+  int bi = -1;
+  bool have = false;
   for (int r = 0; r < p.k; ++r) {
     float s = -INFINITY;
     int i = -1;
@@ -1831,6 +1972,7 @@ int sskd_similarity(const float* d_q, int nq, const float* d_d, int nd, int dim,
 namespace {
 struct ScreenPlan {
   int QB, LK, n_qblocks, n_slices, tiles_per_slice, n_tiles, lists_per_query;
+  int pre_tiles, pre_slices, pre_tps;   // the bound-only pre-pass over the first rows (append form)
   size_t part_elems;
 };
 
@@ -1846,10 +1988,10 @@ bool screen_plan(int64_t n_rows, int nq, int k, ScreenPlan* sp) {
   pl.QB = SSKD_SCREEN_FORCE_QB;  // tools/ab_build.py sweeps only
 #endif
   pl.n_qblocks = (int)sskd::ceil_div(nq, 32 * pl.QB);
-  // Slices: every slice starts its lists and pruning pools cold, which costs ~0.09 ms per slice at
+  // Slices: every slice starts its pruning pools cold, which costs ~0.09 ms per slice at
   // 10 k queries whatever the corpus size (3 -> 6 slices: +0.25 ms at 125 k rows and at 1 M), while a
-  // launch that does not fill whole rounds of the chip's 256 CUs (one 8-wave workgroup per CU: 99 KB of
-  // LDS at QB = 4, 144-152 VGPRs at QB = 2) wastes the idle share of the matrix time.  Pick the round count that minimises
+  // launch that does not fill whole rounds of the chip's 256 CUs (one workgroup per CU: 99 KB of
+  // LDS at QB = 4) wastes the idle share of the matrix time.  Pick the round count that minimises
   //   matrix_time / utilisation + 0.09 ms x slices.
   // 10 k queries: 79 query blocks x 3 slices = 237 workgroups in ONE round (125 k rows: 2.16 -> 1.76 ms,
   // 1 M rows: 9.34 -> 9.16 ms against the former 16 slices in five rounds).
@@ -1866,13 +2008,8 @@ bool screen_plan(int64_t n_rows, int nq, int k, ScreenPlan* sp) {
     const double cost = matrix_ms / util + warm_ms * sl;
     if (cost < best - 1e-9) { best = cost; slices = sl; }
   }
-  // few, long lists hold more of a query's candidate band each: deeper lists keep the "list full inside
-  // the band" fallback (an exact scan of the whole shard for a handful of queries) out of the common path
-  pl.LK = slices * SCREEN_WAVES * 2 < 128 ? 8 : 6;
-#ifdef SSKD_SCREEN_FORCE_LK
-  pl.LK = SSKD_SCREEN_FORCE_LK;
-#endif
-  const int max_by_lists = SCREEN_MAX_ENTRIES / (pl.LK * 2 * SCREEN_WAVES);  // lists = slices * waves * 2
+  pl.LK = SCREEN_CAP;   // entries per run
+  const int max_by_lists = 1024 / (2 * SCREEN_WAVES);   // <= 1 024 runs per query
   if (slices > max_by_lists) slices = max_by_lists;
 #ifdef SSKD_SCREEN_FORCE_SLICES
   slices = SSKD_SCREEN_FORCE_SLICES;
@@ -1880,8 +2017,12 @@ bool screen_plan(int64_t n_rows, int nq, int k, ScreenPlan* sp) {
   pl.tiles_per_slice = (int)sskd::ceil_div(pl.n_tiles, slices);
   pl.n_slices = (int)sskd::ceil_div(pl.n_tiles, pl.tiles_per_slice);
   pl.lists_per_query = pl.n_slices * SCREEN_WAVES * 2;
-  if (pl.lists_per_query * pl.LK > SCREEN_MAX_ENTRIES) return false;
   pl.part_elems = (size_t)nq * pl.lists_per_query * pl.LK;
+  // pre-pass: the first SCREEN_PRE_TILES tiles (at most an eighth of the shard), cut like the main pass so that one
+  // round of workgroups covers it
+  pl.pre_tiles = std::min(SCREEN_PRE_TILES, pl.n_tiles / 8);
+  pl.pre_slices = std::max(1, std::min(pl.n_slices, pl.pre_tiles / SCREEN_WAVES));
+  pl.pre_tps = (int)sskd::ceil_div(pl.pre_tiles, pl.pre_slices);
   *sp = pl;
   return true;
 }
@@ -1889,6 +2030,7 @@ bool screen_plan(int64_t n_rows, int nq, int k, ScreenPlan* sp) {
 struct ScreenWs {
   float* part_scores;
   int* part_ids;
+  int* cand_cnt;     // append form: [nq][lists]
   int* tau;          // [nq] + gpool [nq * 10]
   float* eps2;
   int* fb_count;     // [2]: count, spare
@@ -1911,8 +2053,9 @@ ScreenWs screen_carve(void* base, const ScreenPlan& pl, int64_t n_rows, int nq, 
     return static_cast<void*>(r);
   };
   ScreenWs w{};
-  w.part_scores = static_cast<float*>(take(pl.part_elems * sizeof(float)));
-  w.part_ids = static_cast<int*>(take(pl.part_elems * sizeof(int)));
+  w.part_scores = static_cast<float*>(take(pl.part_elems * sizeof(float)));   // append form: the runs, 8 bytes per entry,
+  w.part_ids = static_cast<int*>(take(pl.part_elems * sizeof(int)));         //   span both arrays (contiguous: see below)
+  w.cand_cnt = static_cast<int*>(take((size_t)nq * pl.lists_per_query * sizeof(int)));
   w.tau = static_cast<int*>(take((size_t)nq * 11 * sizeof(int)));
   w.eps2 = static_cast<float*>(take((size_t)nq * sizeof(float)));
   w.fb_count = static_cast<int*>(take(256));
@@ -2001,50 +2144,53 @@ int sskd_index_search_screened(const float* d_tiled, const void* d_bf16, int64_t
     return sskd::fail(SSKD_ERR_HIP, "index_search_screened: memset failed");
   hipLaunchKernelGGL(screen_eps_kernel, dim3((unsigned)sskd::ceil_div(nq, 4)), dim3(256), 0, st, d_queries, nq, max_norm2, w.eps2);
 
-  ScreenParams sp{};
+  static_assert((SCREEN_CAP * sizeof(float)) % 256 == 0, "the runs span part_scores and part_ids back to back");
+  ScreenAppendParams sp{};
   sp.tiled = static_cast<const sbf16x8*>(d_bf16);
   sp.queries = d_queries;
   sp.eps2 = w.eps2;
-  sp.part_scores = w.part_scores;
-  sp.part_ids = w.part_ids;
+  sp.cand = reinterpret_cast<uint2*>(w.part_scores);
+  sp.cand_cnt = w.cand_cnt;
   sp.tau = w.tau;
   sp.gpool = w.tau + nq;
   sp.n_rows = n_rows;
-  sp.n_tiles = pl.n_tiles;
   sp.nq = nq;
-  sp.n_slices = pl.n_slices;
-  sp.tiles_per_slice = pl.tiles_per_slice;
   sp.lists_per_query = pl.lists_per_query;
   const size_t lds = (size_t)pl.QB * BSTEPS * 64 * 16 + (size_t)pl.QB * 32 * 11 * sizeof(int);
-  if (ev_scan_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_scan_begin), st);
-  const void* kern = nullptr;
-#ifdef SSKD_SCREEN_FORCE_LK
-  if (pl.QB == 4) kern = reinterpret_cast<const void*>(screen_topk_kernel<10, 4, SCREEN_WAVES, SSKD_SCREEN_FORCE_LK>);
-  else kern = reinterpret_cast<const void*>(screen_topk_kernel<10, 2, SCREEN_WAVES, SSKD_SCREEN_FORCE_LK>);
-  if (false)
-#endif
-  if (pl.QB == 4 && pl.LK == 8) kern = reinterpret_cast<const void*>(screen_topk_kernel<10, 4, SCREEN_WAVES, 8>);
-  else if (pl.QB == 4 && pl.LK == 6) kern = reinterpret_cast<const void*>(screen_topk_kernel<10, 4, SCREEN_WAVES, 6>);
-  else if (pl.QB == 2 && pl.LK == 8) kern = reinterpret_cast<const void*>(screen_topk_kernel<10, 2, SCREEN_WAVES, 8>);
-  else if (pl.QB == 2 && pl.LK == 6) kern = reinterpret_cast<const void*>(screen_topk_kernel<10, 2, SCREEN_WAVES, 6>);
-  else return sskd::fail(SSKD_ERR_UNSUPPORTED, "index_search_screened: no screening kernel for QB=%d LK=%d", pl.QB, pl.LK);
+  const void* kern_pre = pl.QB == 4 ? reinterpret_cast<const void*>(screen_append_kernel<10, 4, SCREEN_WAVES, true>)
+                                    : reinterpret_cast<const void*>(screen_append_kernel<10, 2, SCREEN_WAVES, true>);
+  const void* kern = pl.QB == 4 ? reinterpret_cast<const void*>(screen_append_kernel<10, 4, SCREEN_WAVES, false>)
+                                : reinterpret_cast<const void*>(screen_append_kernel<10, 2, SCREEN_WAVES, false>);
+  (void)hipFuncSetAttribute(kern_pre, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (ev_scan_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_scan_begin), st);
+  if (pl.pre_tiles >= SCREEN_WAVES) {   // bound-only pass over the first rows: the main pass starts warm
+    ScreenAppendParams pre = sp;
+    pre.n_tiles = pl.pre_tiles;
+    pre.n_slices = pl.pre_slices;
+    pre.tiles_per_slice = pl.pre_tps;
+    void* args[] = {&pre};
+    if (hipLaunchKernel(kern_pre, dim3(pl.n_qblocks * pl.pre_slices), dim3(SCREEN_WAVES * 64), args, lds, st) != hipSuccess)
+      return sskd::fail(SSKD_ERR_HIP, "index_search_screened: pre-pass launch failed");
+  }
+  sp.n_tiles = pl.n_tiles;
+  sp.n_slices = pl.n_slices;
+  sp.tiles_per_slice = pl.tiles_per_slice;
   {
     void* args[] = {&sp};
     if (hipLaunchKernel(kern, dim3(pl.n_qblocks * pl.n_slices), dim3(SCREEN_WAVES * 64), args, lds, st) != hipSuccess)
       return sskd::fail(SSKD_ERR_HIP, "index_search_screened: screening launch failed");
   }
   if (ev_scan_end) (void)hipEventRecord(static_cast<hipEvent_t>(ev_scan_end), st);
-  int rc = sskd::check_launch("screen_topk_kernel");
+  int rc = sskd::check_launch("screen_append_kernel");
   if (rc != SSKD_OK) return rc;
 
-  ScreenFinalParams fp{};
-  fp.part_scores = w.part_scores;
-  fp.part_ids = w.part_ids;
+  ScreenFinalAppendParams fp{};
+  fp.cand = sp.cand;
+  fp.cand_cnt = w.cand_cnt;
   fp.eps2 = w.eps2;
   fp.rows = reinterpret_cast<const float*>(static_cast<const char*>(d_bf16) + sidecar_rows_offset(n_rows));
   fp.queries = d_queries;
-  fp.K = pl.LK;
   fp.lists = pl.lists_per_query;
   fp.k = k;
   fp.nq = nq;
@@ -2054,9 +2200,9 @@ int sskd_index_search_screened(const float* d_tiled, const void* d_bf16, int64_t
   fp.fb_count = w.fb_count;
   fp.fb_qid = w.fb_qid;
   fp.fb_queries = w.fb_queries;
-  const size_t fin_lds = ((size_t)2 * pl.lists_per_query * pl.LK + DIM + SCREEN_MAX_CAND) * sizeof(float);
-  hipLaunchKernelGGL(screen_finalize_kernel, dim3(nq), dim3(64), fin_lds, st, fp);
-  if ((rc = sskd::check_launch("screen_finalize_kernel")) != SSKD_OK) return rc;
+  const size_t fin_lds = ((size_t)2 * SCREEN_FIN_ENTRIES + DIM + SCREEN_MAX_CAND) * sizeof(float);
+  hipLaunchKernelGGL(screen_finalize_append_kernel, dim3(nq), dim3(64), fin_lds, st, fp);
+  if ((rc = sskd::check_launch("screen_finalize_append_kernel")) != SSKD_OK) return rc;
 
   // exact scan for the queries whose candidate band could not be proven complete (usually none:
   // every workgroup of these launches then exits on its first instruction)

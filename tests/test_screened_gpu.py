@@ -2,7 +2,7 @@
 
 Every case demands the same bits as ``oracle.search.topk_fma`` (the exact path's oracle), i.e. the
 same gate as tests/test_search_gpu.py; on top, the fallback machinery is forced: duplicate-heavy
-corpora (a per-lane list full inside the candidate band -> exact fallback inside the call, for any
+corpora (a candidate band larger than the 256 rows a query re-scores -> exact fallback inside the call, for any
 number of queries), and rows / queries whose every element sits on a bf16 rounding tie with the
 rounding errors of competing rows opposed (the worst case of the error band).
 """
@@ -64,30 +64,87 @@ def test_screened_unnormalised_rows_and_queries(gpu, native_lib):
     assert st[0] == 0 and np.array_equal(i, ref_i) and np.array_equal(s, ref_s)
 
 
-def test_screened_duplicates_take_the_exact_fallback(gpu, native_lib):
-    """40 consecutive copies of one row: for the queries near it the candidate band overflows a
-    per-lane list -> those queries are answered by the exact scan inside the call; ties resolve to
-    the lower id exactly as in the exact path."""
+@pytest.mark.parametrize("copies", [40, 320])
+def test_screened_duplicates(gpu, native_lib, copies):
+    """Consecutive copies of one row next to a quarter of the queries.  40 copies stay inside the candidate band
+    (every row that reaches the pruning bound is appended: nothing is truncated - rounds 2-3 kept 6-deep sorted
+    lists per lane and had to send such queries to the exact scan); 320 copies exceed the 256 candidates a query
+    re-scores, so those queries are answered by the exact scan inside the call.  Either way ties resolve to the
+    lower id exactly as in the exact path."""
     corpus = oracle.seeded_unit_rows(8000, 384, 11)
-    corpus[3000:3040] = corpus[77]
+    corpus[3000:3000 + copies] = corpus[77]
     queries = oracle.seeded_unit_rows(128, 384, 12)
     for j in range(0, 128, 4):
         queries[j] = corpus[77] + 0.02 * queries[j]
         queries[j] /= np.linalg.norm(queries[j])
     s, i, st = screened(native_lib, corpus, queries, 10)
     ref_s, ref_i = oracle.topk_fma(queries, corpus, 10)
-    assert st[0] == 0 and st[1] >= 32          # the planted queries went through the fallback
+    assert st[0] == 0
+    assert st[1] == 0 if copies == 40 else st[1] >= 32, st   # the planted queries went through the fallback (or not)
     assert np.array_equal(i, ref_i) and np.array_equal(s, ref_s)
     assert ref_i[0, 0] == 77 and ref_i[0, 1] == 3000  # equal scores: lower id first
 
 
+def test_screened_ascending_scores_compact_their_runs(gpu, native_lib):
+    """Rows whose score for the planted queries GROWS with the row id: every row is a new best, so every row
+    reaches the pruning bound and a lane's run of 64 appended entries would overflow after four of the five or six
+    tiles a wave owns per slice (512 tiles, 8 slices, 12 waves).  A run that
+    is about to fill up first drops the entries the bound has overtaken, so these queries still come out of the
+    screened path (no exact fallback) with the oracle's bits."""
+    n = 16384
+    u = oracle.seeded_unit_rows(1, 384, 32)[0]
+    noise = oracle.seeded_unit_rows(n, 384, 33)
+    noise -= np.outer(noise @ u, u)                      # orthogonal to u
+    noise /= np.linalg.norm(noise, axis=1, keepdims=True)
+    a = np.linspace(0.05, 0.95, n, dtype=np.float32)[:, None]
+    corpus = (a * u[None] + np.sqrt(1.0 - a * a) * noise).astype(np.float32)
+    queries = oracle.seeded_unit_rows(4096, 384, 34)     # 32 query blocks: 8 slices, several tiles per wave
+    planted = list(range(0, 4096, 2))
+    for j in planted:
+        queries[j] = u + 0.01 * queries[j]
+        queries[j] /= np.linalg.norm(queries[j])
+    s, i, st = screened(native_lib, corpus, queries, 10)
+    sel = list(range(0, 4096, 64))                        # the oracle on a sample of the queries (CPU time)
+    ref_s, ref_i = oracle.topk_fma(queries[sel], corpus, 10)
+    assert st[0] == 0 and st[1] < len(planted) // 4, st
+    assert np.array_equal(i[sel], ref_i) and np.array_equal(s[sel], ref_s)
+    assert (ref_i[0] >= n - 64).all()
+
+
+def test_screened_run_overflow_takes_the_exact_fallback(gpu, native_lib):
+    """80 copies of a row placed where ONE lane's run must take them all (the tiles one wave of one slice owns:
+    every 12th tile, 16 rows per tile and half-wave): 80 entries inside the band exceed the 64 a run holds, no
+    compaction can help, the run's count records the overflow and the planted queries are answered by the exact
+    scan inside the call.  (The band itself - 160 rows - would still fit the 256 candidates a query re-scores.)"""
+    n, nq, waves = 65536, 1024, 12                       # 8 query blocks -> 32 slices of 64 tiles
+    qpb, passes, slices = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    _native.check(native_lib.sskd_index_search_screened_plan(n, nq, 10, ctypes.byref(qpb), ctypes.byref(passes),
+                                                             ctypes.byref(slices)))
+    tiles_per_slice = -(-(n // 32) // slices.value)
+    assert tiles_per_slice >= 4 * waves + 1, (slices.value, tiles_per_slice)
+    corpus = oracle.seeded_unit_rows(n, 384, 41)
+    for t in range(0, 5 * waves, waves):                  # tiles 0, 12, 24, 36, 48 of slice 0: wave 0's
+        corpus[32 * t : 32 * t + 32] = corpus[40000]
+    queries = oracle.seeded_unit_rows(nq, 384, 42)
+    planted = list(range(0, nq, 8))
+    for j in planted:
+        queries[j] = corpus[40000] + 0.02 * queries[j]
+        queries[j] /= np.linalg.norm(queries[j])
+    s, i, st = screened(native_lib, corpus, queries, 10)
+    assert st[0] == 0 and st[1] >= len(planted), st
+    sel = planted[:16] + [1, 2, 3]
+    ref_s, ref_i = oracle.topk_fma(queries[sel], corpus, 10)
+    assert np.array_equal(i[sel], ref_i) and np.array_equal(s[sel], ref_s)
+    assert (ref_i[0] == np.arange(10)).all()             # ten copies, lowest ids first
+
+
 def test_screened_fallback_holds_every_query(gpu, native_lib):
-    """1 200 queries whose candidate band cannot be proven complete (64 copies of their nearest row): the
+    """1 200 queries whose candidate band is too large to re-score (320 copies of their nearest row): the
     in-call exact fallback is sized for every query, so the C-ABI call itself returns the oracle's bits - no
     status to check, no poisoned rows (round 2 capped the fallback at 1 024 queries), on the raw entry point
     and on both product paths."""
     corpus = oracle.seeded_unit_rows(4096, 384, 21)
-    corpus[1000:1064] = corpus[5]
+    corpus[1000:1320] = corpus[5]
     queries = np.repeat(corpus[5][None], 1200, axis=0) + 0.01 * oracle.seeded_unit_rows(1200, 384, 22)
     queries /= np.linalg.norm(queries, axis=1, keepdims=True)
     queries = queries.astype(np.float32)
@@ -251,9 +308,9 @@ def _exact(lib, tiled, n, q, nq, k, id_offset):
 
 
 def test_screened_equals_exact_scan_over_random_launch_geometries(gpu, native_lib):
-    """The launch plan (queries per workgroup, slices, list depth, XCD mapping) is a function of the shape:
+    """The launch plan (queries per workgroup, slices, pre-pass, XCD mapping) is a function of the shape:
     sweep shapes across its regimes - one slice, slices capped by the tile count, query blocks with a
-    ragged tail, 6- and 8-deep lists - and demand the exact scan's bits (that scan is oracle-pinned in
+    ragged tail, shards with and without the bound-only pre-pass - and demand the exact scan's bits (that scan is oracle-pinned in
     tests/test_search_gpu.py).  Clustered rows keep the candidate bands busy."""
     lib = native_lib
     rng = np.random.default_rng(20260)

@@ -103,14 +103,15 @@ def test_sharded_scores_concat_equals_unsharded(tmp_path, n, world):
 
 
 def _sharded_case(n, nq, dups):
-    """Seeded rows / queries; ``dups``: 64 copies of one row inside EACH shard and every query next to it -
-    more than 1 024 queries per rank whose candidate band cannot be proven (round 2: such rows came back
+    """Seeded rows / queries; ``dups``: 320 copies of one row inside EACH shard and every query next to it -
+    more than 1 024 queries per rank whose candidate band holds more rows than the screened search re-scores
+    (256), so the exact fallback answers them (round 2: such rows came back
     poisoned from ``search_device`` and were merged silently; now the call answers them itself)."""
     corpus = oracle.seeded_unit_rows(n, 384, 1234)
     queries = oracle.seeded_unit_rows(nq, 384, 4321)
     if dups:
-        corpus[1000:1064] = corpus[5]
-        corpus[n // 2 + 700 : n // 2 + 764] = corpus[5]
+        corpus[1000:1320] = corpus[5]
+        corpus[n // 2 + 700 : n // 2 + 1020] = corpus[5]
         queries = np.repeat(corpus[5][None], nq, axis=0) + 0.01 * queries
         queries = (queries / np.linalg.norm(queries, axis=1, keepdims=True)).astype(np.float32)
     return corpus, queries

@@ -45,6 +45,7 @@ out_i = torch.empty((NQ, K), dtype=torch.int64, device=dev)
 status = torch.zeros(2, dtype=torch.int32, device=dev)
 times = {n: [] for n, *_ in libs}
 wall = {n: [] for n, *_ in libs}
+fallbacks = {n: 0 for n, *_ in libs}
 for r in range(ROUNDS):
     for n, lib, tiled, bf, ws in libs:
         a, b = C.c_void_p(), C.c_void_p()
@@ -64,9 +65,12 @@ for r in range(ROUNDS):
         ms = C.c_float()
         hip.hipEventSynchronize(b); hip.hipEventElapsedTime(C.byref(ms), a, b)
         times[n].append(ms.value)
+        if not EXACT:
+            fallbacks[n] = max(fallbacks[n], int(status[1]))
         if ref is None:
             ref = (out_s.clone(), out_i.clone())
         if not os.environ.get('AB_NOCHECK'):
             assert torch.equal(out_i, ref[1]) and torch.equal(out_s, ref[0]) and int(status[0]) == 0, n
 for n in times:
-    print(f"{n}: screen kernel median {np.median(times[n][1:]):.3f} ms (min {np.min(times[n][1:]):.3f}); whole call {np.median(wall[n][1:]):.3f} ms", flush=True)
+    print(f"{n}: screen kernel median {np.median(times[n][1:]):.3f} ms (min {np.min(times[n][1:]):.3f}); whole call {np.median(wall[n][1:]):.3f} ms"
+          + ("" if EXACT else f"; exact-fallback queries {fallbacks[n]}"), flush=True)
