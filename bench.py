@@ -593,7 +593,7 @@ def main() -> None:
         _native.check(lib.sskd_index_search_screened_plan(n_local, nq, K, qpb, passes, slices))
         qpb_v, passes_v, slices_v = qpb.value, passes.value, slices.value
         alg_bytes = passes_v * n_local * DIM * 2 + nq * DIM * 4 + nq * K * 12
-        kernel_name, peak_tf = "screen_topk_kernel", MFMA_BF16_PEAK_TF
+        kernel_name, peak_tf = "screen_append_kernel", MFMA_BF16_PEAK_TF
         tpath = REPO / "profiles" / "screen_traffic.json"
     else:
         qpb, passes, slices, waves, scans = (C.c_int() for _ in range(5))
