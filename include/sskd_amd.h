@@ -135,11 +135,14 @@ int sskd_index_search_profiled(const float* d_tiled, int64_t n_rows,
  * The bf16 copy holds the rows MINUS their mean row (q.mean is the same for every row of a query, so
  * ranking is untouched): on anisotropic embeddings (e5: mean pairwise cosine 0.7-0.8) the centred norms,
  * and with them the band, are 2-2.2x smaller.
- * Queries whose candidate band cannot be proven complete (a per-lane list full inside the band:
- * duplicate-heavy neighbourhoods) are answered by the exact scan inside the same call - the in-call
- * fallback is sized for every query, so no output row is ever unproven and callers have nothing to
- * check.  d_status (device int[2]): [0] = always 0 (kept for ABI stability), [1] = the number of
- * queries that took the exact fallback (a cost diagnostic).  d_bf16: the screening sidecar,
+ * Every row whose screen score reaches the running bound (a lower bound of the query's k-th best screen
+ * score, minus the band) is appended to a per-lane run in the workspace, so the appended set always holds
+ * the whole band; a query is answered by the exact scan inside the same call only when its band holds
+ * more than 256 rows (hundreds of near-duplicates of its neighbours) or one run overflowed (> 64 band rows
+ * in one lane's share of a slice) - the in-call fallback is sized for every query, so no output row is
+ * ever unproven and callers have nothing to check.  d_status (device int[2]): [0] = always 0 (kept for ABI
+ * stability), [1] = the number of queries that took the exact fallback (a cost diagnostic).  ev_scan_begin /
+ * ev_scan_end bracket the screening step (bound-only pre-pass over the first rows + main pass).  d_bf16: the screening sidecar,
  * sskd_index_bf16_bytes(n_rows) bytes filled by sskd_index_make_bf16 from the CURRENT tiled index
  * (re-make it after sskd_index_add_rows): the bf16 tiles of the centred rows (768 B per row), a 4-KiB
  * block with max |row|^2, max |row~|^2, max |row~ - (row - mean)|^2 and the column sums, and the ORIGINAL

@@ -6,6 +6,7 @@ Per search CALL: the screening step is two launches of ``screen_append_kernel`` 
 rows, then the main pass); durations and counters are summed over both and divided by the number of main-pass launches.
 FETCH_SIZE is doubled (gfx950 tallies 128-byte requests as 64 bytes), WRITE_SIZE is used as read; both are in KB."""
 import csv
+import re
 import hashlib
 import json
 import subprocess
@@ -21,6 +22,10 @@ NOTE = ("separate rocprofv3 passes (tools/prof_r03.sh): --kernel-trace --stats f
         "tools/ab_search.py (10 000 queries, k = 10, seeded unit rows)")
 
 
+def is_prepass(name: str) -> bool:
+    return re.search(r"screen_append_kernel<[^>]*true>", name.replace(" ", "")) is not None
+
+
 def newest(d: Path, pattern: str):
     files = sorted(d.rglob(pattern), key=lambda f: f.stat().st_mtime)
     return files[-1] if files else None
@@ -34,7 +39,7 @@ def durations(d: Path, key: str):
     calls, cur = [], 0.0
     for r in rows:
         cur += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-        if "true>" not in r["Kernel_Name"].replace(" ", ""):   # the bound-only pre-pass precedes its main pass
+        if not is_prepass(r["Kernel_Name"]):   # the bound-only pre-pass precedes its main pass
             calls.append(cur)
             cur = 0.0
     calls = calls[1:] if len(calls) > 1 else calls              # first call: cold caches / code load
@@ -47,7 +52,7 @@ def counter(d: Path, key: str, name: str):
     for r in csv.DictReader(open(f)):
         if key in r["Kernel_Name"] and r["Counter_Name"] == name:
             tot += float(r["Counter_Value"])
-            if "true>" not in r["Kernel_Name"].replace(" ", ""):
+            if not is_prepass(r["Kernel_Name"]):
                 mains += 1
     return tot / mains
 
