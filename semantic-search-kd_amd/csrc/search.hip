@@ -766,11 +766,19 @@ constexpr int BTILE_VEC = BSTEPS * 64;           // 16-byte vectors per 32-row b
 #ifndef SSKD_SCREEN_RING
 #define SSKD_SCREEN_RING 2
 #endif
-constexpr int BGROUP = SSKD_SCREEN_BGROUP;       // k-steps per prefetch group
-constexpr int BGROUPS = BSTEPS / BGROUP;
+// Tile prefetch ring of a wave: RING register buffers of BGROUP k-steps each, RING - 1 groups in flight.  128 queries
+// per workgroup (64 accumulator registers): 6 k-steps x 2 buffers; 160 queries (80 accumulators): 3 x 2 - what is left
+// of the 168 registers three waves per SIMD allow (tools/ab_search.py sweeps: gpurun_out/r03_sweep*.log, r03_q5*.log)
+constexpr int BGROUP = SSKD_SCREEN_BGROUP;
+constexpr int SCREEN_RING = SSKD_SCREEN_RING;
+constexpr int BGROUP_Q5 = 3, SCREEN_RING_Q5 = 2;
 constexpr int SCREEN_WAVES = SSKD_SCREEN_WAVES;  // waves per screening workgroup
-constexpr int SCREEN_RING = SSKD_SCREEN_RING;    // register buffers of one group each; RING - 1 groups are in flight
-static_assert(BSTEPS % BGROUP == 0 && BGROUPS % SCREEN_RING == 0 && SCREEN_RING >= 2, "screening prefetch geometry");
+template <int BG, int RG>
+struct ScreenRingOk {
+  static_assert(BSTEPS % BG == 0 && (BSTEPS / BG) % RG == 0 && RG >= 2, "screening prefetch geometry");
+  static constexpr bool value = true;
+};
+static_assert(ScreenRingOk<BGROUP, SCREEN_RING>::value && ScreenRingOk<BGROUP_Q5, SCREEN_RING_Q5>::value, "");
 // fp32 accumulation slack of the two dot products, relative to |q| max|c|: the exact score is a 384-step fma
 // chain (<= 384 x 2^-24), the screen score 24 MFMAs of 16 exact products each accumulated in fp32 (<= 2 x 384
 // x 2^-24 even if every internal add truncated); 3 x 384 x 2^-24 (1 + 2^-8)^2 = 6.9e-5, rounded up generously
@@ -892,45 +900,47 @@ __global__ __launch_bounds__(256) void screen_eps_kernel(const float* __restrict
   }
 }
 
-__device__ inline void load_bgroup(sbf16x8 (&buf)[BGROUP], const sbf16x8* __restrict__ base) {
+template <int BG>
+__device__ inline void load_bgroup(sbf16x8 (&buf)[BG], const sbf16x8* __restrict__ base) {
 #pragma unroll
-  for (int s = 0; s < BGROUP; ++s) buf[s] = base[s * 64];
+  for (int s = 0; s < BG; ++s) buf[s] = base[s * 64];
 }
 
 // One group of k-steps.  (A two-deep register pipeline of the LDS query-fragment reads, pinned with
 // sched_group_barrier, was built and measured: 9.6 ms against 8.5 ms for the compiler's own
 // "two reads, wait, MFMA" placement below - the pinned order delays the tile prefetch loads.)
-template <int QB, int G>
-__device__ inline void compute_bgroup(const sbf16x8 (&a)[BGROUP], const sbf16x8* __restrict__ qlane, f32x16 (&acc)[QB]) {
+template <int QB, int G, int BG>
+__device__ inline void compute_bgroup(const sbf16x8 (&a)[BG], const sbf16x8* __restrict__ qlane, f32x16 (&acc)[QB]) {
   asm volatile("" ::: "memory");  // keep the (tile-invariant) LDS query reads inside the group (see compute_group)
 #pragma unroll
-  for (int s = 0; s < BGROUP; ++s) {
+  for (int s = 0; s < BG; ++s) {
 #pragma unroll
     for (int qq = 0; qq < QB; ++qq) {
 #ifdef SSKD_SCREEN_ABL_NOLDS   // timing ablation (tools/ab_search.py, AB_NOCHECK): no LDS query-fragment reads
-      const sbf16x8 b = a[(s + qq) % BGROUP];
+      const sbf16x8 b = a[(s + qq) % BG];
 #else
-      const sbf16x8 b = qlane[(qq * BSTEPS + G * BGROUP + s) * 64];
+      const sbf16x8 b = qlane[(qq * BSTEPS + G * BG + s) * 64];
 #endif
       acc[qq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b, acc[qq], 0, 0, 0);
     }
   }
 }
 
-// one tile's groups, compile-time unrolled over a ring of RING register buffers: group G is multiplied
-// from buffer G % RING while group G + RING - 1 (of this tile, or of the wave's next tile) loads
-template <int QB, int G>
-__device__ inline void screen_tile_groups(sbf16x8 (&buf)[SCREEN_RING][BGROUP], const sbf16x8* __restrict__ tile,
+// one tile's groups, compile-time unrolled over a ring of RG register buffers: group G is multiplied
+// from buffer G % RG while group G + RG - 1 (of this tile, or of the wave's next tile) loads
+template <int QB, int G, int BG, int RG>
+__device__ inline void screen_tile_groups(sbf16x8 (&buf)[RG][BG], const sbf16x8* __restrict__ tile,
                                           const sbf16x8* __restrict__ qlane, f32x16 (&acc)[QB], bool more,
                                           int64_t next_tile) {
-  if constexpr (G < BGROUPS) {
-    constexpr int PG = G + SCREEN_RING - 1;  // group to prefetch now
+  constexpr int NG = BSTEPS / BG;
+  if constexpr (G < NG) {
+    constexpr int PG = G + RG - 1;  // group to prefetch now
 #ifndef SSKD_SCREEN_ABL_NOGLOBAL  // timing ablation: no corpus tile loads (the ring keeps its first contents)
-    if constexpr (PG < BGROUPS) load_bgroup(buf[PG % SCREEN_RING], tile + PG * BGROUP * 64);
-    else if (more) load_bgroup(buf[PG % SCREEN_RING], tile + next_tile + (PG - BGROUPS) * BGROUP * 64);
+    if constexpr (PG < NG) load_bgroup<BG>(buf[PG % RG], tile + PG * BG * 64);
+    else if (more) load_bgroup<BG>(buf[PG % RG], tile + next_tile + (PG - NG) * BG * 64);
 #endif
-    compute_bgroup<QB, G>(buf[G % SCREEN_RING], qlane, acc);
-    screen_tile_groups<QB, G + 1>(buf, tile, qlane, acc, more, next_tile);
+    compute_bgroup<QB, G, BG>(buf[G % RG], qlane, acc);
+    screen_tile_groups<QB, G + 1, BG, RG>(buf, tile, qlane, acc, more, next_tile);
   }
 }
 
@@ -1000,7 +1010,7 @@ __device__ __attribute__((noinline)) int screen_compact_run(unsigned long long* 
   return w;
 }
 
-template <int K, int QB, int WAVES, bool BOUND_ONLY>
+template <int K, int QB, int WAVES, bool BOUND_ONLY, int BG, int RG>
 __global__ __launch_bounds__(WAVES * 64) void screen_append_kernel(ScreenAppendParams p) {
   extern __shared__ float4 qs_raw[];
   sbf16x8* const qs = reinterpret_cast<sbf16x8*>(qs_raw);  // [QB][24 steps][64 lanes]
@@ -1060,11 +1070,11 @@ __global__ __launch_bounds__(WAVES * 64) void screen_append_kernel(ScreenAppendP
   const sbf16x8* lane_base = p.tiled + lane;
   const bool ragged = (p.n_rows & 31) != 0;
 
-  sbf16x8 buf[SCREEN_RING][BGROUP];
+  sbf16x8 buf[RG][BG];
   int t = t_begin + wave;
   if (t < t_end) {
 #pragma unroll
-    for (int g = 0; g + 1 < SCREEN_RING; ++g) load_bgroup(buf[g], lane_base + (int64_t)t * BTILE_VEC + g * BGROUP * 64);
+    for (int g = 0; g + 1 < RG; ++g) load_bgroup<BG>(buf[g], lane_base + (int64_t)t * BTILE_VEC + g * BG * 64);
   }
 
   int tiles_done = 0;
@@ -1092,7 +1102,7 @@ __global__ __launch_bounds__(WAVES * 64) void screen_append_kernel(ScreenAppendP
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[qq][r] = 0.f;
 
-    screen_tile_groups<QB, 0>(buf, tile, qlane, acc, t + WAVES < t_end, (int64_t)WAVES * BTILE_VEC);
+    screen_tile_groups<QB, 0, BG, RG>(buf, tile, qlane, acc, t + WAVES < t_end, (int64_t)WAVES * BTILE_VEC);
 
     const int rowbase = t * TILE_ROWS + 4 * h;
     if (ragged && (int64_t)(t + 1) * TILE_ROWS > p.n_rows) {
@@ -1980,34 +1990,37 @@ bool screen_plan(int64_t n_rows, int nq, int k, ScreenPlan* sp) {
   if (k < 1 || k > 10 || nq < 64 || n_rows < 64 * TILE_ROWS) return false;
   ScreenPlan pl{};
   pl.n_tiles = (int)sskd::ceil_div(n_rows, TILE_ROWS);
-  // 128 queries per workgroup (QB = 4) halve the corpus re-reads per MFMA: at 64 queries the tile loads
-  // from L2 take as long as the MFMAs they feed.  Measured on 125 k .. 1 M rows x 10 k queries
-  // (tools/ab_search.py with the FORCE macros below): QB = 4 wins at every size.
-  pl.QB = nq >= 256 ? 4 : 2;
-#ifdef SSKD_SCREEN_FORCE_QB
-  pl.QB = SSKD_SCREEN_FORCE_QB;  // tools/ab_build.py sweeps only
-#endif
-  pl.n_qblocks = (int)sskd::ceil_div(nq, 32 * pl.QB);
-  // Slices: every slice starts its pruning pools cold, which costs ~0.09 ms per slice at
-  // 10 k queries whatever the corpus size (3 -> 6 slices: +0.25 ms at 125 k rows and at 1 M), while a
-  // launch that does not fill whole rounds of the chip's 256 CUs (one workgroup per CU: 99 KB of
-  // LDS at QB = 4) wastes the idle share of the matrix time.  Pick the round count that minimises
+  // Queries per workgroup x slices.  128 queries per workgroup (QB = 4) halve the corpus re-reads per MFMA against 64;
+  // 160 (QB = 5: 120 KB of B fragments in LDS, 80 accumulator registers, a shorter prefetch ring) cut them by another
+  // fifth and - the reason they are here - change how the launch tiles the chip: 10 000 queries are 79 blocks of 128
+  // (x 3 slices = 237 workgroups on 256 CUs) or 63 blocks of 160 (x 4 = 252).
+  // Slices: every slice starts its pruning pools cold, which costs ~0.09 ms per slice at 10 k queries whatever the
+  // corpus size, while a launch that does not fill whole rounds of the chip's 256 CUs (one workgroup per CU)
+  // wastes the idle share of the matrix time.  Over both block sizes and 1..8 rounds, minimise
   //   matrix_time / utilisation + 0.09 ms x slices.
-  // 10 k queries: 79 query blocks x 3 slices = 237 workgroups in ONE round (125 k rows: 2.16 -> 1.76 ms,
-  // 1 M rows: 9.34 -> 9.16 ms against the former 16 slices in five rounds).
+  // Measured (tools/ab_search.py): 1 M rows 7.90 (128 x 3) -> 7.55 ms (160 x 4); 125 k rows 1.34 (128 x 3) vs 1.39.
   const int resident = SCREEN_CUS;
   const int max_slices = std::max(1, (int)sskd::ceil_div(pl.n_tiles, SCREEN_WAVES));
   const double matrix_ms = (double)n_rows * nq * (2.0 * DIM) / 1.0e12;   // at ~1 PFLOP/s sustained
   const double warm_ms = 0.09 * nq / 10000.0;
   int slices = 1;
   double best = 1e300;
-  for (int rounds = 1; rounds <= 8; ++rounds) {
-    int sl = std::min(std::max(1, rounds * resident / pl.n_qblocks), max_slices);
-    const int wgs = sl * pl.n_qblocks;
-    const double util = (double)wgs / ((double)resident * sskd::ceil_div(wgs, resident));
-    const double cost = matrix_ms / util + warm_ms * sl;
-    if (cost < best - 1e-9) { best = cost; slices = sl; }
+  for (int qb : {4, 5, 2}) {
+    if (qb == 2 ? nq >= 256 : nq < 256) continue;   // small batches: 64 queries per workgroup
+#ifdef SSKD_SCREEN_FORCE_QB
+    if (qb != SSKD_SCREEN_FORCE_QB) continue;        // tools/ab_build.py sweeps only
+#endif
+    const int qblocks = (int)sskd::ceil_div(nq, 32 * qb);
+    for (int rounds = 1; rounds <= 8; ++rounds) {
+      const int sl = std::min(std::max(1, rounds * resident / qblocks), max_slices);
+      const int wgs = sl * qblocks;
+      const double util = (double)wgs / ((double)resident * sskd::ceil_div(wgs, resident));
+      const double cost = matrix_ms / util + warm_ms * sl;
+      if (cost < best - 1e-9) { best = cost; slices = sl; pl.QB = qb; }
+    }
   }
+  if (pl.QB == 0) return false;
+  pl.n_qblocks = (int)sskd::ceil_div(nq, 32 * pl.QB);
   pl.LK = SCREEN_CAP;   // entries per run
   const int max_by_lists = 1024 / (2 * SCREEN_WAVES);   // <= 1 024 runs per query
   if (slices > max_by_lists) slices = max_by_lists;
@@ -2157,10 +2170,21 @@ int sskd_index_search_screened(const float* d_tiled, const void* d_bf16, int64_t
   sp.nq = nq;
   sp.lists_per_query = pl.lists_per_query;
   const size_t lds = (size_t)pl.QB * BSTEPS * 64 * 16 + (size_t)pl.QB * 32 * 11 * sizeof(int);
-  const void* kern_pre = pl.QB == 4 ? reinterpret_cast<const void*>(screen_append_kernel<10, 4, SCREEN_WAVES, true>)
-                                    : reinterpret_cast<const void*>(screen_append_kernel<10, 2, SCREEN_WAVES, true>);
-  const void* kern = pl.QB == 4 ? reinterpret_cast<const void*>(screen_append_kernel<10, 4, SCREEN_WAVES, false>)
-                                : reinterpret_cast<const void*>(screen_append_kernel<10, 2, SCREEN_WAVES, false>);
+  const void* kern_pre = nullptr;
+  const void* kern = nullptr;
+  switch (pl.QB) {
+#define SSKD_SCREEN_CASE(qb, bg, rg)                                                                      \
+  case qb:                                                                                                \
+    kern_pre = reinterpret_cast<const void*>(screen_append_kernel<10, qb, SCREEN_WAVES, true, bg, rg>);   \
+    kern = reinterpret_cast<const void*>(screen_append_kernel<10, qb, SCREEN_WAVES, false, bg, rg>);      \
+    break;
+    SSKD_SCREEN_CASE(2, BGROUP, SCREEN_RING)
+    SSKD_SCREEN_CASE(4, BGROUP, SCREEN_RING)
+    SSKD_SCREEN_CASE(5, BGROUP_Q5, SCREEN_RING_Q5)
+#undef SSKD_SCREEN_CASE
+    default:
+      return sskd::fail(SSKD_ERR_UNSUPPORTED, "index_search_screened: no screening kernel for %d queries per workgroup", 32 * pl.QB);
+  }
   (void)hipFuncSetAttribute(kern_pre, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (ev_scan_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_scan_begin), st);
