@@ -772,6 +772,10 @@ constexpr int BTILE_VEC = BSTEPS * 64;           // 16-byte vectors per 32-row b
 constexpr int BGROUP = SSKD_SCREEN_BGROUP;
 constexpr int SCREEN_RING = SSKD_SCREEN_RING;
 constexpr int BGROUP_Q5 = 3, SCREEN_RING_Q5 = 2;
+#ifndef SSKD_SCREEN_TAU_REFRESH_TILES
+#define SSKD_SCREEN_TAU_REFRESH_TILES 64
+#endif
+constexpr int SCREEN_TAU_REFRESH_TILES = SSKD_SCREEN_TAU_REFRESH_TILES;
 constexpr int SCREEN_WAVES = SSKD_SCREEN_WAVES;  // waves per screening workgroup
 template <int BG, int RG>
 struct ScreenRingOk {
@@ -1080,8 +1084,10 @@ __global__ __launch_bounds__(WAVES * 64) void screen_append_kernel(ScreenAppendP
   int tiles_done = 0;
   for (; t < t_end; t += WAVES, ++tiles_done) {
     const sbf16x8* tile = lane_base + (int64_t)t * BTILE_VEC;
-    const bool exchange = tiles_done < TAU_REFRESH_TILES ? (tiles_done & (tiles_done - 1)) == 0
-                                                         : tiles_done % TAU_REFRESH_TILES == 0;
+    // bounds are exchanged with global memory at tiles 0, 1, 2, 4, ..., 32 and then every 64th: an exchange is ten
+    // dependent agent-scope loads + an atomic per sub-block (~3 us of stall); every 8th tile cost 5 % of the kernel
+    const bool exchange = tiles_done < SCREEN_TAU_REFRESH_TILES ? (tiles_done & (tiles_done - 1)) == 0
+                                                                : tiles_done % SCREEN_TAU_REFRESH_TILES == 0;
 #pragma unroll
     for (int qq = 0; qq < QB; ++qq) {
       const int w = wthr[qq * 32 + j];
@@ -1144,7 +1150,7 @@ __global__ __launch_bounds__(WAVES * 64) void screen_append_kernel(ScreenAppendP
           const float x = acc[qq][r];
           const int xid = rowbase + (r & 3) + 8 * (r >> 2);
           const bool take = real[qq] && x >= gthr[qq];   // (padding queries own no run)
-          if (__any(take)) {
+          {   // (no wave-wide __any() around it: the exec mask skips an empty body, and the test cost more than it saved)
             if (take) {
               if constexpr (!BOUND_ONLY) {
                 unsigned long long* const run = reinterpret_cast<unsigned long long*>(run0 + qq * run_stride);
