@@ -370,8 +370,8 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmArgs p) {
 // 4 token rows x 16 feature columns and each lane receives one column).  That removes the two operand transposes
 // per product the NT kernel needs.  LDS chunk c of token row r holds global chunk c ^ swz(r),
 // swz(r) = 2 (r & 3) ^ 8 ((r >> 3) & 1): the 4 rows of a read and the two groups of a 32-lane half land on
-// different banks.  8 waves as 2 (M) x 4 (N), each 192 x 32 = 12 x 2 tiles of v_mfma_f32_16x16x32_bf16.
-// grid = (output tiles, K slices).
+// different banks.  8 waves as 4 (M) x 2 (N), each 96 x 64 = 6 x 4 tiles of v_mfma_f32_16x16x32_bf16.
+// grid = output tiles x K slices, one-dimensional (the order is XCD-aware: see the kernel).
 // ------------------------------------------------------------------------- //
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -383,6 +383,7 @@ struct GemmTnArgs {
   int64_t lda, ldb, ldc, T;
   int M, N;
   int k_per;   // K tiles (of 64 tokens) per slice
+  int xcd_map; // workgroup order: all tiles of a K slice on one XCD (see the kernel)
 };
 
 __device__ inline int tn_swz(int row) { return (2 * (row & 3)) ^ (8 * ((row >> 3) & 1)); }
@@ -395,11 +396,27 @@ __global__ __launch_bounds__(512) void gemm_tn384_kernel(GemmTnArgs p) {
   bf16_t* const lds = reinterpret_cast<bf16_t*>(gtn_lds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
+  const int wr = wave >> 1, wc = wave & 1;        // 4 (M) x 2 (N) waves, each 96 x 64 = 6 x 4 MFMA tiles: 20 KiB of fragment
+  constexpr int NI = 6, NJ = 4;                   // reads per wave and K tile (2 x 4 waves of 192 x 32 read 28 KiB and were LDS-bound)
+  constexpr int WMF = NI * 16, WNF = NJ * 16;     // features per wave along M and N
   const int tiles_n = p.N / TN;
-  const int m0 = (blockIdx.x / tiles_n) * TM, n0 = (blockIdx.x % tiles_n) * TN;
+  const int tiles = tiles_n * (p.M / TM);
+  // Workgroup -> (K slice, output tile).  xcd_map: the hardware deals consecutive workgroup ids to the 8 XCDs round-robin;
+  // ALL tiles of a K slice go to ONE XCD (id = 8 j + xcd: slice = xcd + 8 (j / tiles), tile = j % tiles), so the token
+  // rows the tiles of a slice share (every tile of an M row reads the same A panel, every tile of an N column the same
+  // B panel) come out of that XCD's L2 once.  Otherwise: tile-major (id = tile + tiles * slice), any slice count.
+  int slice, tile;
+  if (p.xcd_map) {
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    slice = xcd + 8 * (jj / tiles);
+    tile = jj % tiles;
+  } else {
+    slice = blockIdx.x / tiles;
+    tile = blockIdx.x % tiles;
+  }
+  const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TN;
   const int nk_all = (int)(p.T / BK);
-  const int kt0 = blockIdx.y * p.k_per;
+  const int kt0 = slice * p.k_per;
   const int nk = min(p.k_per, nk_all - kt0);
   if (nk <= 0) return;
 
@@ -426,11 +443,11 @@ __global__ __launch_bounds__(512) void gemm_tn384_kernel(GemmTnArgs p) {
     for (int i = 0; i < 2; ++i) glds16(gb + b_off[i], sb + (8 * i + wave) * 512);
   };
 
-  f32x4 acc[12][2];
+  f32x4 acc[NI][NJ];
 #pragma unroll
-  for (int i = 0; i < 12; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // transposed fragment reads: lane 4 q + pp of a 16-lane group supplies the address of token row q, columns 4 pp .. + 3
   const int fr = lane & 15, fq = lane >> 4, q = fr >> 2, pp = fr & 3;
@@ -443,41 +460,41 @@ __global__ __launch_bounds__(512) void gemm_tn384_kernel(GemmTnArgs p) {
     const bf16_t* const sb = sa + TM * BK;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      s16x8 a[12], b[2];
+      s16x8 a[NI], b[NJ];
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         const int row = 32 * kk + 8 * fq + 4 * hh + q, sw = tn_swz(row);
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
-          const int chunk = wr * 24 + 2 * i + (pp >> 1);
+        for (int i = 0; i < NI; ++i) {
+          const int chunk = wr * (WMF / 8) + 2 * i + (pp >> 1);
           const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (__attribute__((address_space(3))) s16x4*)(sa + row * TM + ((chunk ^ sw) << 3) + 4 * (pp & 1)));
           a[i][4 * hh + 0] = v[0]; a[i][4 * hh + 1] = v[1]; a[i][4 * hh + 2] = v[2]; a[i][4 * hh + 3] = v[3];
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int chunk = wc * 4 + 2 * j + (pp >> 1);
+        for (int j = 0; j < NJ; ++j) {
+          const int chunk = wc * (WNF / 8) + 2 * j + (pp >> 1);
           const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (__attribute__((address_space(3))) s16x4*)(sb + row * TN + ((chunk ^ sw) << 3) + 4 * (pp & 1)));
           b[j][4 * hh + 0] = v[0]; b[j][4 * hh + 1] = v[1]; b[j][4 * hh + 2] = v[2]; b[j][4 * hh + 3] = v[3];
         }
       }
 #pragma unroll
-      for (int i = 0; i < 12; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]),
                                                               acc[i][j], 0, 0, 0);
     }
   }
-  // acc[i][j][e] = C[m0 + 192 wr + 16 i + 4 fq + e][n0 + 32 wc + 16 j + fr]
+  // acc[i][j][e] = C[m0 + WMF wr + 16 i + 4 fq + e][n0 + WNF wc + 16 j + fr]
 #pragma unroll
-  for (int i = 0; i < 12; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        atomicAdd(p.C + (int64_t)(m0 + wr * 192 + i * 16 + 4 * fq + e) * p.ldc + n0 + wc * 32 + j * 16 + fr, acc[i][j][e]);
+        atomicAdd(p.C + (int64_t)(m0 + wr * WMF + i * 16 + 4 * fq + e) * p.ldc + n0 + wc * WNF + j * 16 + fr, acc[i][j][e]);
 }
 
 // ------------------------------------------------------------------------- //
@@ -1574,14 +1591,27 @@ int launch_gemm_tn(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, f
   a.N = N;
   const int tiles = (M / 384) * (N / 128);
   const int nk = (int)(T / 64);
-  int split = GEMM256_CUS / tiles;       // one workgroup per CU
-  if (split < 1) split = 1;
-  if (split > nk / 4) split = nk / 4 > 0 ? nk / 4 : 1;  // at least 4 K tiles per slice
+  // K slices, at least 4 K tiles each, every workgroup of the launch resident at once (one per CU).  The tiles of a
+  // slice share operand panels: with slices s, s + 8, ... on XCD s & 7 they come out of ONE L2 (dWo 66 -> 61 us,
+  // dWqkv 117 -> 102, dW1 141 -> 130 at 65 536 tokens) - except for a single row of 12 tiles (dW2: the shared A panel
+  // is small, and whole slices per XCD leave a quarter of the CUs idle: 125 -> 131 us), which keeps the dealt order.
+  a.xcd_map = !(M / 384 == 1 && tiles >= 12);
+  int split;
+  if (a.xcd_map) {
+    int per_xcd = 32 / tiles;
+    if (per_xcd < 1) per_xcd = 1;
+    split = 8 * per_xcd;
+  } else {
+    split = GEMM256_CUS / tiles;
+    if (split < 1) split = 1;
+  }
+  if (split > nk / 4) split = nk / 4 > 0 ? nk / 4 : 1;
   a.k_per = (int)sskd::ceil_div(nk, split);
   split = (int)sskd::ceil_div(nk, a.k_per);
+  const unsigned grid = a.xcd_map ? 8u * (unsigned)(tiles * (int)sskd::ceil_div(split, 8)) : (unsigned)(tiles * split);
   constexpr int lds_bytes = 2 * (384 + 128) * 64 * 2;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn384_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-  hipLaunchKernelGGL(gemm_tn384_kernel, dim3((unsigned)tiles, (unsigned)split), dim3(512), lds_bytes, st, a);
+  hipLaunchKernelGGL(gemm_tn384_kernel, dim3(grid), dim3(512), lds_bytes, st, a);
   return sskd::check_launch("gemm_tn384_kernel");
 }
 

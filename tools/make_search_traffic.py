@@ -23,7 +23,7 @@ NOTE = ("separate rocprofv3 passes (tools/prof_r03.sh): --kernel-trace --stats f
 
 
 def is_prepass(name: str) -> bool:
-    return re.search(r"screen_append_kernel<[^>]*true>", name.replace(" ", "")) is not None
+    return re.search(r"screen_append_kernel<\d+,\d+,\d+,true", name.replace(" ", "")) is not None
 
 
 def newest(d: Path, pattern: str):
@@ -88,7 +88,7 @@ print("wrote", dst)
 if "screen_1m" in out:
     e = out["screen_1m"]
     (REPO / "profiles" / "screen_traffic.json").write_text(json.dumps({
-        "kernel": "screen_append_kernel<10, 4, 12> (pre-pass + main pass)", "hbm_bytes_per_launch": e["hbm_bytes_per_launch"],
+        "kernel": "screen_append_kernel<10, 5, 12, ., 3, 2> (bound-only pre-pass + main pass)", "hbm_bytes_per_launch": e["hbm_bytes_per_launch"],
         "fetch_size_kb": e["fetch_size_kb"], "write_size_kb": e["write_size_kb"], "search_hip_sha": sha, "note": NOTE,
         "from": f"profiles/r03/search_traffic.json@{head}"}, indent=1))
     print("wrote profiles/screen_traffic.json")
