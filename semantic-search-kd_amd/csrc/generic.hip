@@ -191,7 +191,7 @@ __device__ inline void glds16(const void* g, void* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <int BN>   // 256, or 128 for outputs whose width is a multiple of 128 only (the 384-wide student)
+template <int BN>   // 256; 192 for the 384-wide student's outputs (384, 1152: 128 x 48 per wave); 128 for other multiples of 128
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmArgs p) {
   constexpr int BK = 64;
   constexpr int NREP = BN / 64;              // 16-column MFMA tiles per wave (4 waves across N)
@@ -347,10 +347,11 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmArgs p) {
       }
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's own LDS writes (wave-private slice)
       __builtin_amdgcn_wave_barrier();
-      constexpr int CPR = WN / 8;          // 16-byte segments per row: 8 or 4
+      constexpr int CPR = WN / 8;          // 16-byte segments per row: 8, 6 or 4
 #pragma unroll
-      for (int h2 = 0; h2 < 16 * CPR / 64; ++h2) {
+      for (int h2 = 0; h2 < (16 * CPR + 63) / 64; ++h2) {
         const int seg = lane + 64 * h2, row = seg / CPR, c8 = (seg % CPR) * 8;
+        if ((16 * CPR) % 64 != 0 && seg >= 16 * CPR) continue;   // (192-wide tiles: 96 segments)
         const u32x4 val = *reinterpret_cast<const u32x4*>(wt + row * LDW + c8);
         *reinterpret_cast<u32x4*>(Cg + (int64_t)(m0 + wr * 128 + i * 16 + row) * p.ldc + n0 + wc * WN + c8) = val;
       }
@@ -1496,6 +1497,11 @@ int launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
       hipLaunchKernelGGL(kern, dim3((unsigned)(tiles < GEMM256_CUS ? tiles : GEMM256_CUS)), dim3(512), lds256, st, a);
     };
     if (a.N % 256 == 0) go(gemm_nt256_kernel<256>, 256);
+#ifndef SSKD_GEMM_NO_BN192
+    // a 128-column tile leaves a wave 128 x 32: 10 KiB of fragment reads per 16 MFMAs, more than the LDS delivers in
+    // their time; 192 columns (128 x 48 per wave: 11 KiB per 24 MFMAs) fit under it
+    else if (a.N % 192 == 0) go(gemm_nt256_kernel<192>, 192);
+#endif
     else go(gemm_nt256_kernel<128>, 128);
     return sskd::check_launch("gemm_nt256_kernel");
   }
