@@ -706,21 +706,17 @@ __device__ inline void stage_row_frags(bf16x8* dst, const bf16_t* src, int64_t l
         *reinterpret_cast<const bf16x8*>(src + (int64_t)row * ld + 8 * c);
   }
 }
-// the same block transposed: A-operand fragments [dim][row] with the rows of a 32-tile in the order the packed
-// accumulators present them (k index 8h + e' <-> row 16 s2 + 8 (e' >> 2) + 4h + (e' & 3))
+// the same block ROW-MAJOR ([row][DH], swizzled like the forward's V): the transposed A-operand fragments [dim][row] of
+// K, Q and dO - rows of a 32-tile in the order the packed accumulators present them - are gathered by the READ
+// (att_vt_frag: ds_read_b64_tr_b16).  Rounds 2-3 staged them transposed with eight 2-byte LDS stores per 16 bytes
+// loaded: 45 % of this kernel's LDS cycles were bank conflicts of those stores.
 template <int DH>
-__device__ inline void stage_transposed_frags(bf16_t* dst, const bf16_t* src, int64_t ld, int S, int tid) {
-  constexpr int CPK = DH / 8, DT = DH / 32;
+__device__ inline void stage_row_major(bf16_t* dst, const bf16_t* src, int64_t ld, int S, int tid) {
+  constexpr int CPK = DH / 8;
   for (int v = tid; v < S * CPK; v += 512) {
     const int row = v / CPK, c = v - row * CPK;
-    const bf16x8 vv = *reinterpret_cast<const bf16x8*>(src + (int64_t)row * ld + 8 * c);
-    const int kk = row & 31, g = kk >> 3, hh = (kk >> 2) & 1, e = kk & 3;
-    const int s2 = g >> 1, ep = 4 * (g & 1) + e;
-#pragma unroll
-    for (int e8 = 0; e8 < 8; ++e8) {
-      const int d = 8 * c + e8;
-      dst[(((((row >> 5) * DT + (d >> 5)) * 2 + s2) * 64) + (d & 31) + 32 * hh) * 8 + ep] = vv[e8];
-    }
+    *reinterpret_cast<bf16x8*>(reinterpret_cast<unsigned char*>(dst) + row * (DH * 2) + ((16 * c) ^ att_vswz<DH>(row))) =
+        *reinterpret_cast<const bf16x8*>(src + (int64_t)row * ld + 8 * c);
   }
 }
 
@@ -771,9 +767,12 @@ __global__ __launch_bounds__(512) void attention_bwd_kernel(AttnBwdArgs p) {
   stage_row_frags<DH>(vA, qbase + 2 * p.H, ld, p.S, tid);
   stage_row_frags<DH>(qA, qbase, ld, p.S, tid);
   stage_row_frags<DH>(doA, dobase, p.H, p.S, tid);
-  stage_transposed_frags<DH>(reinterpret_cast<bf16_t*>(kT), qbase + p.H, ld, p.S, tid);
-  stage_transposed_frags<DH>(reinterpret_cast<bf16_t*>(qT), qbase, ld, p.S, tid);
-  stage_transposed_frags<DH>(reinterpret_cast<bf16_t*>(doT), dobase, p.H, p.S, tid);
+  const bf16_t* const kR = reinterpret_cast<const bf16_t*>(kT);
+  const bf16_t* const qR = reinterpret_cast<const bf16_t*>(qT);
+  const bf16_t* const doR = reinterpret_cast<const bf16_t*>(doT);
+  stage_row_major<DH>(reinterpret_cast<bf16_t*>(kT), qbase + p.H, ld, p.S, tid);
+  stage_row_major<DH>(reinterpret_cast<bf16_t*>(qT), qbase, ld, p.S, tid);
+  stage_row_major<DH>(reinterpret_cast<bf16_t*>(doT), dobase, p.H, p.S, tid);
   __syncthreads();
   if (wave >= p.nkt) return;
   const int kmax = s_kmax;
@@ -817,8 +816,8 @@ __global__ __launch_bounds__(512) void attention_bwd_kernel(AttnBwdArgs p) {
       }
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
-        dq[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT[((kt * DT + t) * 2 + 0) * 64 + lane], dsf[0], dq[t], 0, 0, 0);
-        dq[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT[((kt * DT + t) * 2 + 1) * 64 + lane], dsf[1], dq[t], 0, 0, 0);
+        dq[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_vt_frag<DH>(kR, kt, t, 0, lane), dsf[0], dq[t], 0, 0, 0);
+        dq[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_vt_frag<DH>(kR, kt, t, 1, lane), dsf[1], dq[t], 0, 0, 0);
       }
     }
 #pragma unroll
@@ -872,10 +871,10 @@ __global__ __launch_bounds__(512) void attention_bwd_kernel(AttnBwdArgs p) {
       }
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
-        dv[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doT[((qt * DT + t) * 2 + 0) * 64 + lane], pf[0], dv[t], 0, 0, 0);
-        dv[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doT[((qt * DT + t) * 2 + 1) * 64 + lane], pf[1], dv[t], 0, 0, 0);
-        dk[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qT[((qt * DT + t) * 2 + 0) * 64 + lane], dsf[0], dk[t], 0, 0, 0);
-        dk[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qT[((qt * DT + t) * 2 + 1) * 64 + lane], dsf[1], dk[t], 0, 0, 0);
+        dv[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_vt_frag<DH>(doR, qt, t, 0, lane), pf[0], dv[t], 0, 0, 0);
+        dv[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_vt_frag<DH>(doR, qt, t, 1, lane), pf[1], dv[t], 0, 0, 0);
+        dk[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_vt_frag<DH>(qR, qt, t, 0, lane), dsf[0], dk[t], 0, 0, 0);
+        dk[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_vt_frag<DH>(qR, qt, t, 1, lane), dsf[1], dk[t], 0, 0, 0);
       }
     }
 #pragma unroll
