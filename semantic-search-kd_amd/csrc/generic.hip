@@ -720,19 +720,23 @@ __device__ inline void stage_row_major(bf16_t* dst, const bf16_t* src, int64_t l
   }
 }
 
-template <int DH>
+// PASS 0 = pass A (dQ: needs K and V as row fragments, K row-major: 3 blocks of LDS), PASS 1 = pass B (dK, dV: Q and dO
+// as row fragments and row-major: 4 blocks).  One kernel doing both held all 7 blocks (112 KiB at S = 256, DH = 32: ONE
+// workgroup per CU, and each workgroup is a chain of short dependent MFMA groups); split, three and two fit.
+template <int DH, int PASS>
 __global__ __launch_bounds__(512) void attention_bwd_kernel(AttnBwdArgs p) {
   constexpr int KS = DH / 16, DT = DH / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char att_lds[];
   const int SD8 = p.S * DH / 8;  // bf16x8 vectors of one [S][DH] block
-  bf16x8* const kA = reinterpret_cast<bf16x8*>(att_lds);
-  bf16x8* const vA = kA + SD8;
-  bf16x8* const qA = vA + SD8;
-  bf16x8* const doA = qA + SD8;
-  bf16x8* const kT = doA + SD8;
-  bf16x8* const qT = kT + SD8;
-  bf16x8* const doT = qT + SD8;
-  float* const lse = reinterpret_cast<float*>(doT + SD8);
+  bf16x8* const blk0 = reinterpret_cast<bf16x8*>(att_lds);
+  bf16x8* const kA = blk0;                                 // pass A: kA, vA, kT      pass B: qA, doA, qT, doT
+  bf16x8* const vA = blk0 + SD8;
+  bf16x8* const kT = blk0 + 2 * SD8;
+  bf16x8* const qA = blk0;
+  bf16x8* const doA = blk0 + SD8;
+  bf16x8* const qT = blk0 + 2 * SD8;
+  bf16x8* const doT = blk0 + 3 * SD8;
+  float* const lse = reinterpret_cast<float*>(blk0 + (PASS == 0 ? 3 : 4) * SD8);
   float* const Dq = lse + p.S;
   float* const mb = Dq + p.S;
   __shared__ int s_kmax;
@@ -763,16 +767,19 @@ __global__ __launch_bounds__(512) void attention_bwd_kernel(AttnBwdArgs p) {
     }
     Dq[i] = dsum;
   }
-  stage_row_frags<DH>(kA, qbase + p.H, ld, p.S, tid);
-  stage_row_frags<DH>(vA, qbase + 2 * p.H, ld, p.S, tid);
-  stage_row_frags<DH>(qA, qbase, ld, p.S, tid);
-  stage_row_frags<DH>(doA, dobase, p.H, p.S, tid);
   const bf16_t* const kR = reinterpret_cast<const bf16_t*>(kT);
   const bf16_t* const qR = reinterpret_cast<const bf16_t*>(qT);
   const bf16_t* const doR = reinterpret_cast<const bf16_t*>(doT);
-  stage_row_major<DH>(reinterpret_cast<bf16_t*>(kT), qbase + p.H, ld, p.S, tid);
-  stage_row_major<DH>(reinterpret_cast<bf16_t*>(qT), qbase, ld, p.S, tid);
-  stage_row_major<DH>(reinterpret_cast<bf16_t*>(doT), dobase, p.H, p.S, tid);
+  if constexpr (PASS == 0) {
+    stage_row_frags<DH>(kA, qbase + p.H, ld, p.S, tid);
+    stage_row_frags<DH>(vA, qbase + 2 * p.H, ld, p.S, tid);
+    stage_row_major<DH>(reinterpret_cast<bf16_t*>(kT), qbase + p.H, ld, p.S, tid);
+  } else {
+    stage_row_frags<DH>(qA, qbase, ld, p.S, tid);
+    stage_row_frags<DH>(doA, dobase, p.H, p.S, tid);
+    stage_row_major<DH>(reinterpret_cast<bf16_t*>(qT), qbase, ld, p.S, tid);
+    stage_row_major<DH>(reinterpret_cast<bf16_t*>(doT), dobase, p.H, p.S, tid);
+  }
   __syncthreads();
   if (wave >= p.nkt) return;
   const int kmax = s_kmax;
@@ -780,12 +787,16 @@ __global__ __launch_bounds__(512) void attention_bwd_kernel(AttnBwdArgs p) {
   bf16_t* const drow = p.dqkv + (row0 + wave * 32 + j) * ld + (int64_t)head * DH;  // this lane's row of dQ | dK | dV
 
   // ---- pass A: dQ of query tile `wave` ----
-  {
+  if constexpr (PASS == 0) {
     bf16x8 qB[KS], doB[KS];
+    {   // B operand of a row block = its row fragment: row j of the tile, 8 features from 8 h of every 16-feature step
+      const bf16_t* qrow = qbase + (int64_t)(wave * 32 + j) * ld + 8 * h;
+      const bf16_t* dorow = dobase + (int64_t)(wave * 32 + j) * p.H + 8 * h;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      qB[s] = qA[(wave * KS + s) * 64 + lane];     // B operand of a row block = its row fragment
-      doB[s] = doA[(wave * KS + s) * 64 + lane];
+      for (int s = 0; s < KS; ++s) {
+        qB[s] = *reinterpret_cast<const bf16x8*>(qrow + 16 * s);
+        doB[s] = *reinterpret_cast<const bf16x8*>(dorow + 16 * s);
+      }
     }
     const float lse_q = lse[wave * 32 + j], d_q = Dq[wave * 32 + j];
     f32x16 dq[DT];
@@ -832,12 +843,15 @@ __global__ __launch_bounds__(512) void attention_bwd_kernel(AttnBwdArgs p) {
   }
 
   // ---- pass B: dK, dV of key tile `wave` ----
-  {
+  if constexpr (PASS == 1) {
     bf16x8 kB[KS], vB[KS];
+    {
+      const bf16_t* krow = qbase + p.H + (int64_t)(wave * 32 + j) * ld + 8 * h;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      kB[s] = kA[(wave * KS + s) * 64 + lane];
-      vB[s] = vA[(wave * KS + s) * 64 + lane];
+      for (int s = 0; s < KS; ++s) {
+        kB[s] = *reinterpret_cast<const bf16x8*>(krow + 16 * s);
+        vB[s] = *reinterpret_cast<const bf16x8*>(krow + p.H + 16 * s);
+      }
     }
     const float mbk = mb[wave * 32 + j];
     f32x16 dk[DT], dv[DT];
@@ -1563,13 +1577,18 @@ int launch_attention_bwd(const bf16_t* qkv, const int32_t* key_mask, const bf16_
   a.nkt = S / 32;
   a.scale = scale;
   a.scale2 = scale * 1.4426950408889634f;
-  const size_t lds = (size_t)7 * S * DH * 2 + (size_t)3 * S * sizeof(float);
-  auto go = [&](auto kern) {
+  auto go = [&](auto kern, int blocks) {
+    const size_t lds = (size_t)blocks * S * DH * 2 + (size_t)3 * S * sizeof(float);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)(B * heads)), dim3(512), lds, st, a);
   };
-  if (DH == 32) go(attention_bwd_kernel<32>);
-  else go(attention_bwd_kernel<64>);
+  if (DH == 32) {
+    go(attention_bwd_kernel<32, 0>, 3);
+    go(attention_bwd_kernel<32, 1>, 4);
+  } else {
+    go(attention_bwd_kernel<64, 0>, 3);
+    go(attention_bwd_kernel<64, 1>, 4);
+  }
   return sskd::check_launch("attention_bwd_kernel");
 }
 
