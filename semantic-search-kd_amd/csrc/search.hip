@@ -1130,6 +1130,20 @@ __global__ __launch_bounds__(WAVES * 64) void screen_append_kernel(ScreenAppendP
       float m = acc[qq][0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[qq][r]);
+      if constexpr (BOUND_ONLY) {
+        // the pre-pass only needs a bound: ONE offer per lane and tile (its best row) instead of one per row - every
+        // row of a cold sample passes, and 80 compare-and-swap loops per lane and tile made the pre-pass 0.1 ms
+        if (real[qq] && m >= gthr[qq]) {
+          int xid = rowbase;
+#pragma unroll
+          for (int r = 15; r >= 0; --r) xid = acc[qq][r] == m ? rowbase + (r & 3) + 8 * (r >> 2) : xid;
+          const int xi = float_to_ordered(m);
+          if (pool_offer<K>(pool + (qq * 32 + j) * K, wthr + qq * 32 + j, xi))
+            (void)__hip_atomic_fetch_max(p.gpool + (int64_t)(q0 + qq * 32 + j) * K + xid % K, xi, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+          gthr[qq] = fmaxf(gthr[qq], ordered_to_float(wthr[qq * 32 + j]) - band[qq]);
+        }
+      } else
       if (__any(real[qq] && m >= gthr[qq])) {
 #ifndef SSKD_SCREEN_NO_COMPACT
         if constexpr (!BOUND_ONLY) {
