@@ -730,7 +730,7 @@ __global__ __launch_bounds__(64) void similarity_kernel(const float* __restrict_
 // faster, so a SCREENING pass computes every score from bf16-rounded rows and queries first.
 // Error bound, PROVED and data-dependent: with q~, c~ the rounded vectors,
 //   q~.c~ - q.c = (q~ - q).c~ + q.(c~ - c),  so  |q~.c~ - q.c| <= |q~ - q| |c~| + |q| |c~ - c|  (Cauchy-Schwarz).
-// |q~ - q| and |q| are MEASURED per query (screen_eps_kernel; q - q~ is exact in fp32), max |c~|, max |c~ - c|
+// |q~ - q| and |q| are MEASURED per query (screen_setup_kernel; q - q~ is exact in fp32), max |c~|, max |c~ - c|
 // and max |c| over the rows are MEASURED when the bf16 copy is made (make_bf16_tiles_kernel).  On top,
 // SCREEN_ACC_SLACK |q| max|c| covers the fp32 accumulation roundings of both dot products.  Worst case
 // (every element on a bf16 tie: relative rounding error 2^-8 per element, bf16 has 8 significand bits) this
@@ -879,9 +879,22 @@ __global__ __launch_bounds__(256) void make_bf16_tiles_kernel(const float4* __re
   if (threadIdx.x < 96) atomicMax(norm_block + (threadIdx.x >> 5), __float_as_int(rowss[threadIdx.x >> 5][threadIdx.x & 31]));
 }
 
-// per query: 2e = 2 (|q~ - q| max|c~| + |q| max|c~ - c| + SCREEN_ACC_SLACK |q| max|c|), rounded UP
-__global__ __launch_bounds__(256) void screen_eps_kernel(const float* __restrict__ queries, int nq,
-                                                         const int* __restrict__ max_norm2, float* __restrict__ eps2) {
+// One set-up launch per call.  Per query: 2e = 2 (|q~ - q| max|c~| + |q| max|c~ - c| + SCREEN_ACC_SLACK |q| max|c|),
+// rounded UP; and the call's scratch state: tau + the global buckets (11 words per query) to "empty", the fallback
+// counters and the status words to zero (these were four launches / memsets: on a 125 k-row shard the short launches
+// of a call add up to a tenth of it).
+__global__ __launch_bounds__(256) void screen_setup_kernel(const float* __restrict__ queries, int nq,
+                                                           const int* __restrict__ max_norm2, float* __restrict__ eps2,
+                                                           int* __restrict__ tau, int* __restrict__ fb_count,
+                                                           int* __restrict__ d_status) {
+  if (threadIdx.x < 44) {   // this block's 4 queries x 11 words
+    const int64_t i = (int64_t)blockIdx.x * 44 + threadIdx.x;
+    if (i < (int64_t)nq * 11) tau[i] = (int)0x80000000;
+  }
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < 64) fb_count[threadIdx.x] = 0;
+    if (threadIdx.x < 2) d_status[threadIdx.x] = 0;
+  }
   const int lane = threadIdx.x & 63;
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= nq) return;
@@ -1084,10 +1097,10 @@ __global__ __launch_bounds__(WAVES * 64) void screen_append_kernel(ScreenAppendP
   int tiles_done = 0;
   for (; t < t_end; t += WAVES, ++tiles_done) {
     const sbf16x8* tile = lane_base + (int64_t)t * BTILE_VEC;
-    // bounds are exchanged with global memory at tiles 0, 1, 2, 4, ..., 32 and then every 64th: an exchange is ten
-    // dependent agent-scope loads + an atomic per sub-block (~3 us of stall); every 8th tile cost 5 % of the kernel
-    const bool exchange = tiles_done < SCREEN_TAU_REFRESH_TILES ? (tiles_done & (tiles_done - 1)) == 0
-                                                                : tiles_done % SCREEN_TAU_REFRESH_TILES == 0;
+    // bounds are exchanged with global memory at tile 0 (the pre-pass's bound), tile 16 and every 64th: an exchange is
+    // ten dependent agent-scope loads + an atomic per sub-block (~3 us of stall); at tiles 0, 1, 2, 4, 8, 16, ... and
+    // every 8th it cost 5 % of the kernel at 1 M rows and 10 % on a 125 k-row shard.  The pre-pass never reads them.
+    const bool exchange = !BOUND_ONLY && (tiles_done == 0 || tiles_done == 16 || tiles_done % SCREEN_TAU_REFRESH_TILES == 0);
 #pragma unroll
     for (int qq = 0; qq < QB; ++qq) {
       const int w = wthr[qq * 32 + j];
@@ -1395,8 +1408,8 @@ __global__ __launch_bounds__(64) void screen_finalize_append_kernel(ScreenFinalA
       const int row = ci[idx];
       const float4* src = reinterpret_cast<const float4*>(p.rows) + (int64_t)row * (DIM / 4);
       float acc = 0.f;
-#pragma unroll 8
-      for (int u = 0; u < STEPS; ++u) {  // 8 steps = two whole 128-byte lines of the row in flight
+#pragma unroll 16
+      for (int u = 0; u < STEPS; ++u) {  // 16 steps = four whole 128-byte lines of the row in flight
         const float4 a = src[2 * u], b = src[2 * u + 1];
         const float4 qa = *reinterpret_cast<const float4*>(&qv[8 * u]), qb = *reinterpret_cast<const float4*>(&qv[8 * u + 4]);
         acc = fmaf(a.x, qa.x, acc); acc = fmaf(b.x, qb.x, acc);
@@ -1447,8 +1460,10 @@ __global__ void screen_fallback_tiers_kernel(int* __restrict__ fb_count, int tie
 __global__ __launch_bounds__(256) void screen_scatter_kernel(const int* __restrict__ fb_count, const int* __restrict__ fb_qid,
                                                              const float* __restrict__ fb_scores,
                                                              const int64_t* __restrict__ fb_ids, int k,
-                                                             float* __restrict__ out_scores, int64_t* __restrict__ out_ids) {
+                                                             float* __restrict__ out_scores, int64_t* __restrict__ out_ids,
+                                                             int* __restrict__ d_status) {
   const int n = *fb_count;
+  if (blockIdx.x == 0 && threadIdx.x == 0) d_status[1] = n;   // cost diagnostic: queries that took the exact fallback
   for (int i = blockIdx.x; i < n; i += gridDim.x) {
     const int q = fb_qid[i];
     for (int r = threadIdx.x; r < k; r += 256) {
@@ -2171,11 +2186,8 @@ int sskd_index_search_screened(const float* d_tiled, const void* d_bf16, int64_t
   const int64_t tiles = sskd::ceil_div(n_rows, TILE_ROWS);
   const int* max_norm2 = reinterpret_cast<const int*>(static_cast<const char*>(d_bf16) + sidecar_norm_offset(n_rows));
 
-  hipLaunchKernelGGL(fill_int_kernel, dim3((unsigned)sskd::ceil_div(nq * 11, 256)), dim3(256), 0, st, w.tau, nq * 11,
-                     (int)0x80000000);
-  if (hipMemsetAsync(w.fb_count, 0, 256, st) != hipSuccess || hipMemsetAsync(d_status, 0, 2 * sizeof(int), st) != hipSuccess)
-    return sskd::fail(SSKD_ERR_HIP, "index_search_screened: memset failed");
-  hipLaunchKernelGGL(screen_eps_kernel, dim3((unsigned)sskd::ceil_div(nq, 4)), dim3(256), 0, st, d_queries, nq, max_norm2, w.eps2);
+  hipLaunchKernelGGL(screen_setup_kernel, dim3((unsigned)sskd::ceil_div(nq, 4)), dim3(256), 0, st, d_queries, nq, max_norm2,
+                     w.eps2, w.tau, w.fb_count, d_status);
 
   static_assert((SCREEN_CAP * sizeof(float)) % 256 == 0, "the runs span part_scores and part_ids back to back");
   ScreenAppendParams sp{};
@@ -2262,10 +2274,8 @@ int sskd_index_search_screened(const float* d_tiled, const void* d_bf16, int64_t
     if (rc != SSKD_OK) return rc;
   }
   hipLaunchKernelGGL(screen_scatter_kernel, dim3(64), dim3(256), 0, st, w.fb_count, w.fb_qid, w.fb_scores, w.fb_ids, k,
-                     d_out_scores, d_out_ids);
+                     d_out_scores, d_out_ids, d_status);
   if ((rc = sskd::check_launch("screen_scatter_kernel")) != SSKD_OK) return rc;
-  if (hipMemcpyAsync(d_status + 1, w.fb_count, sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess)
-    return sskd::fail(SSKD_ERR_HIP, "index_search_screened: status copy failed");
   return SSKD_OK;
 }
 
