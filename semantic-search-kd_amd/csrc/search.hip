@@ -163,7 +163,10 @@ __device__ inline int float_to_ordered(float x) {
   return b >= 0 ? b : b ^ 0x7FFFFFFF;
 }
 __device__ inline float ordered_to_float(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF); }
-constexpr int TAU_REFRESH_TILES = 8;  // exchange bounds with global memory every this many tiles
+#ifndef SSKD_TAU_REFRESH_TILES
+#define SSKD_TAU_REFRESH_TILES 8
+#endif
+constexpr int TAU_REFRESH_TILES = SSKD_TAU_REFRESH_TILES;  // exchange bounds with global memory every this many tiles
 
 // Workgroup pool.  A single list's K-th entry is a weak bound (a list sees 1/128 of a query's
 // rows).  Every row a lane accepts is therefore also offered to a per-query pool of K slots in LDS
