@@ -1013,11 +1013,13 @@ struct ScreenAppendParams {
   int* tau;
   int* gpool;
   int64_t n_rows;
-  int n_tiles;              // tiles this launch covers (the pre-pass: the sample)
+  int n_tiles;
   int nq;
   int n_slices;
   int tiles_per_slice;
   int lists_per_query;
+  int pre_tiles;            // the sample: the shard's first tiles, pre_tps of them per slice (0: no sample phase)
+  int pre_tps;
 };
 
 // out of line: the cold path must not cost the screening loop registers
@@ -1030,66 +1032,14 @@ __device__ __attribute__((noinline)) int screen_compact_run(unsigned long long* 
   return w;
 }
 
+// One phase of the screening kernel: the tiles [t_begin, t_end) of this workgroup, one tile per wave at a time.
+// BOUND_ONLY: nothing is appended and nothing exchanged - one pool offer per lane and tile (the sample phase).
 template <int K, int QB, int WAVES, bool BOUND_ONLY, int BG, int RG>
-__global__ __launch_bounds__(WAVES * 64) void screen_append_kernel(ScreenAppendParams p) {
-  extern __shared__ float4 qs_raw[];
-  sbf16x8* const qs = reinterpret_cast<sbf16x8*>(qs_raw);  // [QB][24 steps][64 lanes]
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 31, h = lane >> 5;
-  // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8) and each XCD has its own L2: give XCD x
-  // a CONTIGUOUS range of (slice, query block) pairs, slice-major, so that a slice's tiles are pulled
-  // through one or two L2s instead of all eight.
-  const int n_qblocks = gridDim.x / p.n_slices;
-  const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
-  const int logical = xcd * (gridDim.x >> 3) + min(xcd, (int)(gridDim.x & 7)) + within;
-  const int slice = logical / n_qblocks;
-  const int qblk = logical % n_qblocks;
-  const int q0 = qblk * (32 * QB);
-
-  for (int idx = tid; idx < QB * BSTEPS * 64; idx += WAVES * 64) {
-    const int l = idx & 63, sidx = (idx >> 6) % BSTEPS, qq = idx / (64 * BSTEPS);
-    const int q = q0 + qq * 32 + (l & 31);
-    sbf16x8 v;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
-    if (q < p.nq) {
-      const float4* src = reinterpret_cast<const float4*>(p.queries + (int64_t)q * DIM + 16 * sidx + 8 * (l >> 5));
-      const float4 a = src[0], b = src[1];
-      v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
-      v[4] = (__bf16)b.x; v[5] = (__bf16)b.y; v[6] = (__bf16)b.z; v[7] = (__bf16)b.w;
-    }
-    qs[idx] = v;
-  }
-  int* const pool = reinterpret_cast<int*>(qs + QB * BSTEPS * 64);
-  int* const wthr = pool + QB * 32 * K;
-  for (int i = tid; i < QB * 32 * (K + 1); i += WAVES * 64) pool[i] = (int)0x80000000;
-  __syncthreads();
-  const sbf16x8* qlane = qs + lane;
-
-  float gthr[QB];   // best known lower bound on the query's final K-th SCREEN score, minus 2e
-  float band[QB];
-  int cnt[QB];
-  bool real[QB];
-#pragma unroll
-  for (int qq = 0; qq < QB; ++qq) {
-    gthr[qq] = -FLT_MAX;   // finite: the -inf scores of rows past n_rows never pass
-    const int qg = q0 + qq * 32 + j;
-    real[qq] = qg < p.nq;
-    band[qq] = p.eps2[real[qq] ? qg : p.nq - 1];
-    cnt[qq] = 0;
-  }
-  // run of (query q0 + j, this wave, this half-wave); sub-block qq is 32 queries further
-  const int my_list = (slice * WAVES + wave) * 2 + h;
-  uint2* const run0 = p.cand + ((int64_t)min(q0 + j, p.nq - 1) * p.lists_per_query + my_list) * SCREEN_CAP;
-  const int64_t run_stride = (int64_t)32 * p.lists_per_query * SCREEN_CAP;
-
-  const int t_begin = slice * p.tiles_per_slice;
-  const int t_end = min(t_begin + p.tiles_per_slice, p.n_tiles);
-  const sbf16x8* lane_base = p.tiled + lane;
-  const bool ragged = (p.n_rows & 31) != 0;
-
+__device__ __forceinline__ void screen_tiles(const ScreenAppendParams& p, int t_begin, int t_end, int wave, int j, int h, int q0,
+                                             const sbf16x8* __restrict__ lane_base, const sbf16x8* __restrict__ qlane,
+                                             int* __restrict__ pool, int* __restrict__ wthr, uint2* run0, int64_t run_stride,
+                                             bool ragged, float (&gthr)[QB], const float (&band)[QB], int (&cnt)[QB],
+                                             const bool (&real)[QB]) {
   sbf16x8 buf[RG][BG];
   int t = t_begin + wave;
   if (t < t_end) {
@@ -1147,7 +1097,7 @@ __global__ __launch_bounds__(WAVES * 64) void screen_append_kernel(ScreenAppendP
 #pragma unroll
       for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[qq][r]);
       if constexpr (BOUND_ONLY) {
-        // the pre-pass only needs a bound: ONE offer per lane and tile (its best row) instead of one per row - every
+        // the sample phase only needs a bound: ONE offer per lane and tile (its best row) instead of one per row - every
         // row of a cold sample passes, and 80 compare-and-swap loops per lane and tile made the pre-pass 0.1 ms
         if (real[qq] && m >= gthr[qq]) {
           int xid = rowbase;
@@ -1162,7 +1112,7 @@ __global__ __launch_bounds__(WAVES * 64) void screen_append_kernel(ScreenAppendP
       } else
       if (__any(real[qq] && m >= gthr[qq])) {
 #ifndef SSKD_SCREEN_NO_COMPACT
-        if constexpr (!BOUND_ONLY) {
+        {
           // A run that could fill up inside this tile (16 rows) first drops what the bound has overtaken since it was
           // appended: rows arriving in ascending order of their score - a corpus sorted by topic - pass the bound one
           // after the other and the bound follows them, so the entries worth keeping are the band of the CURRENT
@@ -1182,7 +1132,7 @@ __global__ __launch_bounds__(WAVES * 64) void screen_append_kernel(ScreenAppendP
           const bool take = real[qq] && x >= gthr[qq];   // (padding queries own no run)
           {   // (no wave-wide __any() around it: the exec mask skips an empty body, and the test cost more than it saved)
             if (take) {
-              if constexpr (!BOUND_ONLY) {
+              {
                 unsigned long long* const run = reinterpret_cast<unsigned long long*>(run0 + qq * run_stride);
                 if (cnt[qq] < SCREEN_CAP)
                   run[cnt[qq]] = (unsigned long long)__float_as_uint(x) | ((unsigned long long)(unsigned)xid << 32);
@@ -1207,16 +1157,92 @@ __global__ __launch_bounds__(WAVES * 64) void screen_append_kernel(ScreenAppendP
     }
   }
 
+}
+
+template <int K, int QB, int WAVES, int BG, int RG>
+__global__ __launch_bounds__(WAVES * 64) void screen_append_kernel(ScreenAppendParams p) {
+  extern __shared__ float4 qs_raw[];
+  sbf16x8* const qs = reinterpret_cast<sbf16x8*>(qs_raw);  // [QB][24 steps][64 lanes]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8) and each XCD has its own L2: give XCD x
+  // a CONTIGUOUS range of (slice, query block) pairs, slice-major, so that a slice's tiles are pulled
+  // through one or two L2s instead of all eight.
+  const int n_qblocks = gridDim.x / p.n_slices;
+  const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+  const int logical = xcd * (gridDim.x >> 3) + min(xcd, (int)(gridDim.x & 7)) + within;
+  const int slice = logical / n_qblocks;
+  const int qblk = logical % n_qblocks;
+  const int q0 = qblk * (32 * QB);
+
+  for (int idx = tid; idx < QB * BSTEPS * 64; idx += WAVES * 64) {
+    const int l = idx & 63, sidx = (idx >> 6) % BSTEPS, qq = idx / (64 * BSTEPS);
+    const int q = q0 + qq * 32 + (l & 31);
+    sbf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+    if (q < p.nq) {
+      const float4* src = reinterpret_cast<const float4*>(p.queries + (int64_t)q * DIM + 16 * sidx + 8 * (l >> 5));
+      const float4 a = src[0], b = src[1];
+      v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
+      v[4] = (__bf16)b.x; v[5] = (__bf16)b.y; v[6] = (__bf16)b.z; v[7] = (__bf16)b.w;
+    }
+    qs[idx] = v;
+  }
+  int* const pool = reinterpret_cast<int*>(qs + QB * BSTEPS * 64);
+  int* const wthr = pool + QB * 32 * K;
+  for (int i = tid; i < QB * 32 * (K + 1); i += WAVES * 64) pool[i] = (int)0x80000000;
+  __syncthreads();
+  const sbf16x8* qlane = qs + lane;
+
+  float gthr[QB];   // best known lower bound on the query's final K-th SCREEN score, minus 2e
+  float band[QB];
+  int cnt[QB];
+  bool real[QB];
+#pragma unroll
+  for (int qq = 0; qq < QB; ++qq) {
+    gthr[qq] = -FLT_MAX;   // finite: the -inf scores of rows past n_rows never pass
+    const int qg = q0 + qq * 32 + j;
+    real[qq] = qg < p.nq;
+    band[qq] = p.eps2[real[qq] ? qg : p.nq - 1];
+    cnt[qq] = 0;
+  }
+  // run of (query q0 + j, this wave, this half-wave); sub-block qq is 32 queries further
+  const int my_list = (slice * WAVES + wave) * 2 + h;
+  uint2* const run0 = p.cand + ((int64_t)min(q0 + j, p.nq - 1) * p.lists_per_query + my_list) * SCREEN_CAP;
+  const int64_t run_stride = (int64_t)32 * p.lists_per_query * SCREEN_CAP;
+
+  const sbf16x8* lane_base = p.tiled + lane;
+  const bool ragged = (p.n_rows & 31) != 0;
+
+  // Two phases.  0: this workgroup's share of the SAMPLE (the shard's first pre_tiles tiles, cut over the slices),
+  // bounds only - one pool offer per lane and tile, nothing appended, no exchange; its result is published through tau
+  // and the global buckets.  1: its slice, appending.  (The pre-pass was a launch of its own until the fixed costs of a
+  // 125 k-row shard were counted: launch gap + a second staging of the query block = 70 us of a 1.3 ms call.  Two
+  // instantiations of the tile loop, not one loop with a run-time flag: that cost the 160-query kernel 5 spilled
+  // registers and 4 % at 8.8 M rows.)
+  if (p.pre_tps > 0) {
+    const int s_begin = slice * p.pre_tps;
+    screen_tiles<K, QB, WAVES, true, BG, RG>(p, s_begin, min(s_begin + p.pre_tps, p.pre_tiles), wave, j, h, q0, lane_base, qlane,
+                                             pool, wthr, run0, run_stride, ragged, gthr, band, cnt, real);
+    // what this workgroup learned from its share of the sample; everybody's offers are in before phase 1
+#pragma unroll
+    for (int qq = 0; qq < QB; ++qq)
+      if (real[qq] && h == 0) atomicMax(p.tau + q0 + qq * 32 + j, wthr[qq * 32 + j]);
+    __syncthreads();
+  }
+  {
+    const int t_begin = slice * p.tiles_per_slice;
+    screen_tiles<K, QB, WAVES, false, BG, RG>(p, t_begin, min(t_begin + p.tiles_per_slice, p.n_tiles), wave, j, h, q0, lane_base,
+                                              qlane, pool, wthr, run0, run_stride, ragged, gthr, band, cnt, real);
+  }
+
 #pragma unroll
   for (int qq = 0; qq < QB; ++qq) {
     const int q = q0 + qq * 32 + j;
-    if (q < p.nq) {
-      if constexpr (BOUND_ONLY) {
-        if (h == 0) atomicMax(p.tau + q, wthr[qq * 32 + j]);   // what this workgroup learned from its share of the sample
-      } else {
-        p.cand_cnt[(int64_t)q * p.lists_per_query + my_list] = cnt[qq];
-      }
-    }
+    if (q < p.nq) p.cand_cnt[(int64_t)q * p.lists_per_query + my_list] = cnt[qq];
   }
 }
 
@@ -2069,11 +2095,10 @@ bool screen_plan(int64_t n_rows, int nq, int k, ScreenPlan* sp) {
   pl.n_slices = (int)sskd::ceil_div(pl.n_tiles, pl.tiles_per_slice);
   pl.lists_per_query = pl.n_slices * SCREEN_WAVES * 2;
   pl.part_elems = (size_t)nq * pl.lists_per_query * pl.LK;
-  // pre-pass: the first SCREEN_PRE_TILES tiles (at most an eighth of the shard), cut like the main pass so that one
-  // round of workgroups covers it
+  // sample phase: the first SCREEN_PRE_TILES tiles (at most an eighth of the shard), cut over the slices
   pl.pre_tiles = std::min(SCREEN_PRE_TILES, pl.n_tiles / 8);
-  pl.pre_slices = std::max(1, std::min(pl.n_slices, pl.pre_tiles / SCREEN_WAVES));
-  pl.pre_tps = (int)sskd::ceil_div(pl.pre_tiles, pl.pre_slices);
+  pl.pre_slices = pl.n_slices;
+  pl.pre_tps = (int)sskd::ceil_div(pl.pre_tiles, pl.n_slices);
   *sp = pl;
   return true;
 }
@@ -2205,13 +2230,11 @@ int sskd_index_search_screened(const float* d_tiled, const void* d_bf16, int64_t
   sp.nq = nq;
   sp.lists_per_query = pl.lists_per_query;
   const size_t lds = (size_t)pl.QB * BSTEPS * 64 * 16 + (size_t)pl.QB * 32 * 11 * sizeof(int);
-  const void* kern_pre = nullptr;
   const void* kern = nullptr;
   switch (pl.QB) {
 #define SSKD_SCREEN_CASE(qb, bg, rg)                                                                      \
   case qb:                                                                                                \
-    kern_pre = reinterpret_cast<const void*>(screen_append_kernel<10, qb, SCREEN_WAVES, true, bg, rg>);   \
-    kern = reinterpret_cast<const void*>(screen_append_kernel<10, qb, SCREEN_WAVES, false, bg, rg>);      \
+    kern = reinterpret_cast<const void*>(screen_append_kernel<10, qb, SCREEN_WAVES, bg, rg>);             \
     break;
     SSKD_SCREEN_CASE(2, BGROUP, SCREEN_RING)
     SSKD_SCREEN_CASE(4, BGROUP, SCREEN_RING)
@@ -2220,21 +2243,13 @@ int sskd_index_search_screened(const float* d_tiled, const void* d_bf16, int64_t
     default:
       return sskd::fail(SSKD_ERR_UNSUPPORTED, "index_search_screened: no screening kernel for %d queries per workgroup", 32 * pl.QB);
   }
-  (void)hipFuncSetAttribute(kern_pre, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (ev_scan_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_scan_begin), st);
-  if (pl.pre_tiles >= SCREEN_WAVES) {   // bound-only pass over the first rows: the main pass starts warm
-    ScreenAppendParams pre = sp;
-    pre.n_tiles = pl.pre_tiles;
-    pre.n_slices = pl.pre_slices;
-    pre.tiles_per_slice = pl.pre_tps;
-    void* args[] = {&pre};
-    if (hipLaunchKernel(kern_pre, dim3(pl.n_qblocks * pl.pre_slices), dim3(SCREEN_WAVES * 64), args, lds, st) != hipSuccess)
-      return sskd::fail(SSKD_ERR_HIP, "index_search_screened: pre-pass launch failed");
-  }
   sp.n_tiles = pl.n_tiles;
   sp.n_slices = pl.n_slices;
   sp.tiles_per_slice = pl.tiles_per_slice;
+  sp.pre_tiles = pl.pre_tiles >= SCREEN_WAVES ? pl.pre_tiles : 0;   // sample phase: the main pass starts warm
+  sp.pre_tps = sp.pre_tiles ? pl.pre_tps : 0;
   {
     void* args[] = {&sp};
     if (hipLaunchKernel(kern, dim3(pl.n_qblocks * pl.n_slices), dim3(SCREEN_WAVES * 64), args, lds, st) != hipSuccess)

@@ -2,8 +2,8 @@
 ``profiles/screen_traffic.json`` (what ``bench.py`` reads for ``roofline.traffic``):
 ``python tools/make_search_traffic.py gpurun_out/r03_prof``.
 
-Per search CALL: the screening step is two launches of ``screen_append_kernel`` (the bound-only pre-pass over the first
-rows, then the main pass); durations and counters are summed over both and divided by the number of main-pass launches.
+Per search CALL: the screening step is ONE launch of ``screen_append_kernel`` (its bound-only sample phase runs inside
+it; builds that still launch a separate pre-pass - template argument ``true`` - are summed per call).
 FETCH_SIZE is doubled (gfx950 tallies 128-byte requests as 64 bytes), WRITE_SIZE is used as read; both are in KB."""
 import csv
 import re
@@ -18,7 +18,7 @@ REPO = Path(__file__).resolve().parent.parent
 root = Path(sys.argv[1])
 NOTE = ("separate rocprofv3 passes (tools/prof_r03.sh): --kernel-trace --stats for durations, --pmc FETCH_SIZE and --pmc "
         "WRITE_SIZE alone for traffic; FETCH_SIZE doubled per the gfx950 rule (128-B requests tallied as 64 B), WRITE_SIZE as "
-        "read; HBM bytes = (2 FETCH + WRITE) x 1024 per search call (pre-pass + main pass of the screening kernel); program "
+        "read; HBM bytes = (2 FETCH + WRITE) x 1024 per search call (one launch of the screening kernel); program "
         "tools/ab_search.py (10 000 queries, k = 10, seeded unit rows)")
 
 
@@ -88,7 +88,7 @@ print("wrote", dst)
 if "screen_1m" in out:
     e = out["screen_1m"]
     (REPO / "profiles" / "screen_traffic.json").write_text(json.dumps({
-        "kernel": "screen_append_kernel<10, 5, 12, ., 3, 2> (bound-only pre-pass + main pass)", "hbm_bytes_per_launch": e["hbm_bytes_per_launch"],
+        "kernel": "screen_append_kernel<10, 5, 12, 3, 2> (sample phase + slice phase in one launch)", "hbm_bytes_per_launch": e["hbm_bytes_per_launch"],
         "fetch_size_kb": e["fetch_size_kb"], "write_size_kb": e["write_size_kb"], "search_hip_sha": sha, "note": NOTE,
         "from": f"profiles/r03/search_traffic.json@{head}"}, indent=1))
     print("wrote profiles/screen_traffic.json")

@@ -1,7 +1,6 @@
 """Summarise rocprofv3 CSV output: per-kernel mean duration (kernel_trace) and per-kernel mean counter values
 (counter_collection).  ``python tools/pmc_summary.py <dir>``; ``PMC_KEYS=a,b`` keeps only the kernels whose name
-contains one of the keys.  (The screened search launches ``screen_append_kernel`` twice per call - pre-pass and main
-pass - and the means below are per LAUNCH: double them for per-call figures.)"""
+contains one of the keys."""
 import csv
 import os
 import sys
