@@ -142,7 +142,7 @@ int sskd_index_search_profiled(const float* d_tiled, int64_t n_rows,
  * in one lane's share of a slice) - the in-call fallback is sized for every query, so no output row is
  * ever unproven and callers have nothing to check.  d_status (device int[2]): [0] = always 0 (kept for ABI
  * stability), [1] = the number of queries that took the exact fallback (a cost diagnostic).  ev_scan_begin /
- * ev_scan_end bracket the screening step (bound-only pre-pass over the first rows + main pass).  d_bf16: the screening sidecar,
+ * ev_scan_end bracket the screening launch (a bound-only sample phase over the shard's first rows, then the slices).  d_bf16: the screening sidecar,
  * sskd_index_bf16_bytes(n_rows) bytes filled by sskd_index_make_bf16 from the CURRENT tiled index
  * (re-make it after sskd_index_add_rows): the bf16 tiles of the centred rows (768 B per row), a 4-KiB
  * block with max |row|^2, max |row~|^2, max |row~ - (row - mean)|^2 and the column sums, and the ORIGINAL

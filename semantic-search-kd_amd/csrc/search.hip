@@ -986,23 +986,26 @@ __device__ inline void wave_argbest(float& s, int& i) {
 // band" failure mode that sent near-duplicate neighbourhoods to the exact scan.)  Without the lists the kernel fits
 // THREE waves per SIMD (12 waves per workgroup, 168 registers): 8.6 -> 7.8 ms at the bench shape, 1.66 -> 1.30 ms on
 // the 125 k-row shard of an 8-GPU split.
-// A PRE-PASS (BOUND_ONLY = true) runs the same kernel over the first SCREEN_PRE_TILES x 32 rows and only publishes
-// its bounds (tau + the global buckets): the main pass then starts from the k-th best of that sample instead of
-// -inf, which cuts the appended entries per query from ~1 400 (every slice starts cold: its first tiles pass whole)
-// to a few hundred.
+// A SAMPLE PHASE (screen_tiles<..., BOUND_ONLY = true>) opens the launch: every workgroup runs the tile loop over its
+// share of the first SCREEN_PRE_TILES x 32 rows and only publishes bounds (tau + the global buckets); its slice then
+// starts from the k-th best of that sample instead of -inf, which cuts the appended entries per query from ~1 400
+// (every slice starts cold: its first tiles pass whole) to a few hundred.
 // ------------------------------------------------------------------------- //
 #ifndef SSKD_SCREEN_CAP
 #define SSKD_SCREEN_CAP 64
 #endif
 #ifndef SSKD_SCREEN_FIN_ENTRIES
-#define SSKD_SCREEN_FIN_ENTRIES 1024
+#define SSKD_SCREEN_FIN_ENTRIES 640
 #endif
 constexpr int SCREEN_CAP = SSKD_SCREEN_CAP;   // entries per (query, wave, half-wave) run
 #ifndef SSKD_SCREEN_PRE_TILES
 #define SSKD_SCREEN_PRE_TILES 64
 #endif
-constexpr int SCREEN_PRE_TILES = SSKD_SCREEN_PRE_TILES;   // rows / 32 of the bound-only pre-pass
-constexpr int SCREEN_FIN_ENTRIES = SSKD_SCREEN_FIN_ENTRIES;   // appended entries of one query staged in LDS by the finalize kernel
+constexpr int SCREEN_PRE_TILES = SSKD_SCREEN_PRE_TILES;   // rows / 32 of the bound-only sample phase
+// appended entries of one query staged in LDS by the finalize kernel (more: its streaming path).  640 entries = 7.6 KiB
+// per one-wave workgroup with the query and the candidate list; 1 024 cost the 125 k-row shard 3 % (occupancy)
+constexpr int SCREEN_FIN_ENTRIES = SSKD_SCREEN_FIN_ENTRIES;
+static_assert(SCREEN_FIN_ENTRIES >= 640, "the streaming path of the finalize kernel parks 64 x 10 scores in the stage");
 
 struct ScreenAppendParams {
   const sbf16x8* tiled;     // bf16 tiles
@@ -1050,9 +1053,9 @@ __device__ __forceinline__ void screen_tiles(const ScreenAppendParams& p, int t_
   int tiles_done = 0;
   for (; t < t_end; t += WAVES, ++tiles_done) {
     const sbf16x8* tile = lane_base + (int64_t)t * BTILE_VEC;
-    // bounds are exchanged with global memory at tile 0 (the pre-pass's bound), tile 16 and every 64th: an exchange is
+    // bounds are exchanged with global memory at tile 0 (the sample phases' bounds), tile 16 and every 64th: an exchange is
     // ten dependent agent-scope loads + an atomic per sub-block (~3 us of stall); at tiles 0, 1, 2, 4, 8, 16, ... and
-    // every 8th it cost 5 % of the kernel at 1 M rows and 10 % on a 125 k-row shard.  The pre-pass never reads them.
+    // every 8th it cost 5 % of the kernel at 1 M rows and 10 % on a 125 k-row shard.  The sample phase never reads them.
     const bool exchange = !BOUND_ONLY && (tiles_done == 0 || tiles_done == 16 || tiles_done % SCREEN_TAU_REFRESH_TILES == 0);
 #pragma unroll
     for (int qq = 0; qq < QB; ++qq) {
@@ -1098,7 +1101,7 @@ __device__ __forceinline__ void screen_tiles(const ScreenAppendParams& p, int t_
       for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[qq][r]);
       if constexpr (BOUND_ONLY) {
         // the sample phase only needs a bound: ONE offer per lane and tile (its best row) instead of one per row - every
-        // row of a cold sample passes, and 80 compare-and-swap loops per lane and tile made the pre-pass 0.1 ms
+        // row of a cold sample passes, and 80 compare-and-swap loops per lane and tile cost 0.05 ms per call
         if (real[qq] && m >= gthr[qq]) {
           int xid = rowbase;
 #pragma unroll
@@ -2046,7 +2049,7 @@ int sskd_similarity(const float* d_q, int nq, const float* d_d, int nd, int dim,
 namespace {
 struct ScreenPlan {
   int QB, LK, n_qblocks, n_slices, tiles_per_slice, n_tiles, lists_per_query;
-  int pre_tiles, pre_slices, pre_tps;   // the bound-only pre-pass over the first rows (append form)
+  int pre_tiles, pre_slices, pre_tps;   // the bound-only sample phase over the first rows
   size_t part_elems;
 };
 
