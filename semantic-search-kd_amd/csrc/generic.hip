@@ -1034,6 +1034,10 @@ constexpr int LN_BWD_ROWS = 64;  // rows per workgroup (16 per wave)
 // dy2 (optional): the incoming gradient is dy + dy2 (the residual branch's share), added in fp32 on the fly - the
 // separate add kernel and its 3 passes over [tokens, hidden] are gone.  dz may alias dy or dy2: a wave reads its whole
 // row into registers before it writes.
+// NI = 16-byte pieces per lane and row (1: hidden <= 512, 2: <= 1024).  A wave takes RU = 2 rows per trip (4: no better) and requests
+// every row's pieces before it reduces any: with one row in flight the kernel ran at 65 % of the copy rate (every row
+// is a load -> wave reduction -> store chain).
+template <int NI, int RU>   // RU rows per trip
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, const bf16_t* dy2, const bf16_t* __restrict__ z,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, int64_t M, int H,
@@ -1041,9 +1045,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, const bf1
                                                      float* __restrict__ dbeta, float* __restrict__ dz_colsum) {
   __shared__ float red[3][1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float dg[2][8], db[2][8], gm[2][8], dzs[2][8];
+  float dg[NI][8], db[NI][8], gm[NI][8], dzs[NI][8];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NI; ++i) {
     const int c = (lane + 64 * i) * 8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -1051,28 +1055,43 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, const bf1
       gm[i][j] = c < H ? gamma[c + j] : 0.f;
     }
   }
-  for (int r = 0; r < LN_BWD_ROWS / 4; ++r) {
-    const int64_t row = (int64_t)blockIdx.x * LN_BWD_ROWS + wave * (LN_BWD_ROWS / 4) + r;
-    if (row >= M) break;
-    const float mu = mean[row], rs = rstd[row];
-    float g[2][8], xh[2][8];
-    float s1 = 0.f, s2 = 0.f;
+  const int64_t row0 = (int64_t)blockIdx.x * LN_BWD_ROWS + wave * (LN_BWD_ROWS / 4);
+  for (int r = 0; r < LN_BWD_ROWS / 4; r += RU) {
+    if (row0 + r >= M) break;
+    bf16x8 dv[RU][NI], zv[RU][NI], d2[RU][NI];
+    float mu[RU], rs[RU];
+    bool live[RU];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = (lane + 64 * i) * 8;
+    for (int u = 0; u < RU; ++u) {   // every row's loads first
+      const int64_t row = row0 + r + u;
+      live[u] = row < M;
+      mu[u] = live[u] ? mean[row] : 0.f;
+      rs[u] = live[u] ? rstd[row] : 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) g[i][j] = xh[i][j] = 0.f;
-      if (c < H) {
-        const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dy + row * H + c);
-        const bf16x8 zv = *reinterpret_cast<const bf16x8*>(z + row * H + c);
-        bf16x8 d2;
+      for (int i = 0; i < NI; ++i) {
+        const int c = (lane + 64 * i) * 8;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) d2[j] = (bf16_t)0.f;
-        if (dy2) d2 = *reinterpret_cast<const bf16x8*>(dy2 + row * H + c);
+        for (int j = 0; j < 8; ++j) dv[u][i][j] = zv[u][i][j] = d2[u][i][j] = (bf16_t)0.f;
+        if (live[u] && c < H) {
+          dv[u][i] = *reinterpret_cast<const bf16x8*>(dy + row * H + c);
+          zv[u][i] = *reinterpret_cast<const bf16x8*>(z + row * H + c);
+          if (dy2) d2[u][i] = *reinterpret_cast<const bf16x8*>(dy2 + row * H + c);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      if (!live[u]) continue;
+      const int64_t row = row0 + r + u;
+      float g[NI][8], xh[NI][8];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const bool on = (lane + 64 * i) * 8 < H;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float d = (float)dv[j] + (float)d2[j];
-          xh[i][j] = ((float)zv[j] - mu) * rs;
+          const float d = (float)dv[u][i][j] + (float)d2[u][i][j];
+          xh[i][j] = on ? ((float)zv[u][i][j] - mu[u]) * rs[u] : 0.f;
           g[i][j] = d * gm[i][j];
           dg[i][j] += d * xh[i][j];
           db[i][j] += d;
@@ -1080,20 +1099,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, const bf1
           s2 += g[i][j] * xh[i][j];
         }
       }
-    }
-    s1 = wave_sum(s1) / H;
-    s2 = wave_sum(s2) / H;
+      s1 = wave_sum(s1) / H;
+      s2 = wave_sum(s2) / H;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = (lane + 64 * i) * 8;
-      if (c < H) {
-        bf16x8 o;
+      for (int i = 0; i < NI; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < H) {
+          bf16x8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          o[j] = (bf16_t)(rs * (g[i][j] - s1 - xh[i][j] * s2));
-          dzs[i][j] += (float)o[j];  // column sums of dz as stored: the bias gradient of the product that made z
+          for (int j = 0; j < 8; ++j) {
+            o[j] = (bf16_t)(rs[u] * (g[i][j] - s1 - xh[i][j] * s2));
+            dzs[i][j] += (float)o[j];  // column sums of dz as stored: the bias gradient of the product that made z
+          }
+          *reinterpret_cast<bf16x8*>(dz + row * H + c) = o;
         }
-        *reinterpret_cast<bf16x8*>(dz + row * H + c) = o;
       }
     }
   }
@@ -1101,7 +1120,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, const bf1
   for (int w = 0; w < 4; ++w) {
     if (wave == w) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < NI; ++i) {
         const int c = (lane + 64 * i) * 8;
         if (c < H)
 #pragma unroll
@@ -1664,8 +1683,12 @@ int launch_ln_bwd(const bf16_t* dy, const bf16_t* z, const float* mean, const fl
                   const bf16_t* dy2) {
   SSKD_REQUIRE(H % 8 == 0 && H <= 1024, "layernorm: hidden=%d must be a multiple of 8, at most 1024", H);
   if (M == 0) return SSKD_OK;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)sskd::ceil_div(M, LN_BWD_ROWS)), dim3(256), 0, st, dy, dy2, z, mean, rstd,
-                     gamma, M, H, dz, dgamma, dbeta, dz_colsum);
+  if (H <= 512)
+    hipLaunchKernelGGL((ln_bwd_kernel<1, 2>), dim3((unsigned)sskd::ceil_div(M, LN_BWD_ROWS)), dim3(256), 0, st, dy, dy2, z, mean,
+                       rstd, gamma, M, H, dz, dgamma, dbeta, dz_colsum);
+  else
+    hipLaunchKernelGGL((ln_bwd_kernel<2, 2>), dim3((unsigned)sskd::ceil_div(M, LN_BWD_ROWS)), dim3(256), 0, st, dy, dy2, z, mean,
+                       rstd, gamma, M, H, dz, dgamma, dbeta, dz_colsum);
   return sskd::check_launch("ln_bwd_kernel");
 }
 
