@@ -796,6 +796,7 @@ constexpr int SCREEN_MAX_CAND = 256;             // candidates re-scored per que
 // the usual case - still fills the chip), the rest to a launch planned for nq - TIER1 (only duplicate-flooded corpora
 // ever get there).  Both read their actual query count from device memory; with none, every workgroup exits at once.
 constexpr int SCREEN_FALLBACK_TIER1 = 1024;
+constexpr int64_t SCREEN_LIGHT_MAX_ROWS = 500000;   // shards up to this size keep their pools with one offer per lane and tile
 constexpr int SCREEN_CUS = 256;                  // MI355X: the launch geometry is planned in whole rounds of the chip
 
 // fp32 tiled corpus -> bf16 tiled corpus in A-operand order of v_mfma_f32_32x32x16_bf16:
@@ -1037,7 +1038,7 @@ __device__ __attribute__((noinline)) int screen_compact_run(unsigned long long* 
 
 // One phase of the screening kernel: the tiles [t_begin, t_end) of this workgroup, one tile per wave at a time.
 // BOUND_ONLY: nothing is appended and nothing exchanged - one pool offer per lane and tile (the sample phase).
-template <int K, int QB, int WAVES, bool BOUND_ONLY, int BG, int RG>
+template <int K, int QB, int WAVES, bool BOUND_ONLY, bool LIGHT, int BG, int RG>
 __device__ __forceinline__ void screen_tiles(const ScreenAppendParams& p, int t_begin, int t_end, int wave, int j, int h, int q0,
                                              const sbf16x8* __restrict__ lane_base, const sbf16x8* __restrict__ qlane,
                                              int* __restrict__ pool, int* __restrict__ wthr, uint2* run0, int64_t run_stride,
@@ -1141,7 +1142,7 @@ __device__ __forceinline__ void screen_tiles(const ScreenAppendParams& p, int t_
                   run[cnt[qq]] = (unsigned long long)__float_as_uint(x) | ((unsigned long long)(unsigned)xid << 32);
                 ++cnt[qq];   // (> SCREEN_CAP: the run overflowed - the band itself holds more than a run: exact fallback)
               }
-              if (tiles_done > 0) {
+              if (!LIGHT && tiles_done > 0) {
                 const int xi = float_to_ordered(x);
                 if (pool_offer<K>(pool + (qq * 32 + j) * K, wthr + qq * 32 + j, xi) && real[qq])
                   (void)__hip_atomic_fetch_max(p.gpool + (int64_t)(q0 + qq * 32 + j) * K + xid % K, xi,
@@ -1152,8 +1153,21 @@ __device__ __forceinline__ void screen_tiles(const ScreenAppendParams& p, int t_
           }
         }
         if (grew) {
-          // first tile: every workgroup starts at the same instant - offer only the lane's best row
-          if (tiles_done == 0) pool_offer<K>(pool + (qq * 32 + j) * K, wthr + qq * 32 + j, float_to_ordered(m));
+          if constexpr (LIGHT) {
+            // ONE pool offer per lane, sub-block and tile - its best row - instead of one per appended row.  The bound
+            // is a little weaker (two of a query's best rows in one lane's share of a tile count once) and its upkeep
+            // much cheaper: worth it while a slice is short (125 k-row shard -6 %, 60 k -12 %; 1 M rows +1 %, 8.8 M +3 %)
+            int xid = rowbase;
+#pragma unroll
+            for (int r = 15; r >= 0; --r) xid = acc[qq][r] == m ? rowbase + (r & 3) + 8 * (r >> 2) : xid;
+            const int xi = float_to_ordered(m);
+            if (pool_offer<K>(pool + (qq * 32 + j) * K, wthr + qq * 32 + j, xi) && tiles_done > 0)
+              (void)__hip_atomic_fetch_max(p.gpool + (int64_t)(q0 + qq * 32 + j) * K + xid % K, xi, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+          } else {
+            // first tile: every workgroup starts at the same instant - offer only the lane's best row
+            if (tiles_done == 0) pool_offer<K>(pool + (qq * 32 + j) * K, wthr + qq * 32 + j, float_to_ordered(m));
+          }
           gthr[qq] = fmaxf(gthr[qq], ordered_to_float(wthr[qq * 32 + j]) - band[qq]);
         }
       }
@@ -1162,7 +1176,7 @@ __device__ __forceinline__ void screen_tiles(const ScreenAppendParams& p, int t_
 
 }
 
-template <int K, int QB, int WAVES, int BG, int RG>
+template <int K, int QB, int WAVES, bool LIGHT, int BG, int RG>
 __global__ __launch_bounds__(WAVES * 64) void screen_append_kernel(ScreenAppendParams p) {
   extern __shared__ float4 qs_raw[];
   sbf16x8* const qs = reinterpret_cast<sbf16x8*>(qs_raw);  // [QB][24 steps][64 lanes]
@@ -1228,7 +1242,7 @@ __global__ __launch_bounds__(WAVES * 64) void screen_append_kernel(ScreenAppendP
   // registers and 4 % at 8.8 M rows.)
   if (p.pre_tps > 0) {
     const int s_begin = slice * p.pre_tps;
-    screen_tiles<K, QB, WAVES, true, BG, RG>(p, s_begin, min(s_begin + p.pre_tps, p.pre_tiles), wave, j, h, q0, lane_base, qlane,
+    screen_tiles<K, QB, WAVES, true, LIGHT, BG, RG>(p, s_begin, min(s_begin + p.pre_tps, p.pre_tiles), wave, j, h, q0, lane_base, qlane,
                                              pool, wthr, run0, run_stride, ragged, gthr, band, cnt, real);
     // what this workgroup learned from its share of the sample; everybody's offers are in before phase 1
 #pragma unroll
@@ -1238,7 +1252,7 @@ __global__ __launch_bounds__(WAVES * 64) void screen_append_kernel(ScreenAppendP
   }
   {
     const int t_begin = slice * p.tiles_per_slice;
-    screen_tiles<K, QB, WAVES, false, BG, RG>(p, t_begin, min(t_begin + p.tiles_per_slice, p.n_tiles), wave, j, h, q0, lane_base,
+    screen_tiles<K, QB, WAVES, false, LIGHT, BG, RG>(p, t_begin, min(t_begin + p.tiles_per_slice, p.n_tiles), wave, j, h, q0, lane_base,
                                               qlane, pool, wthr, run0, run_stride, ragged, gthr, band, cnt, real);
   }
 
@@ -2050,6 +2064,7 @@ namespace {
 struct ScreenPlan {
   int QB, LK, n_qblocks, n_slices, tiles_per_slice, n_tiles, lists_per_query;
   int pre_tiles, pre_slices, pre_tps;   // the bound-only sample phase over the first rows
+  bool light;                           // short slices: one pool offer per lane and tile (screen_tiles<LIGHT>)
   size_t part_elems;
 };
 
@@ -2099,6 +2114,7 @@ bool screen_plan(int64_t n_rows, int nq, int k, ScreenPlan* sp) {
   pl.lists_per_query = pl.n_slices * SCREEN_WAVES * 2;
   pl.part_elems = (size_t)nq * pl.lists_per_query * pl.LK;
   // sample phase: the first SCREEN_PRE_TILES tiles (at most an eighth of the shard), cut over the slices
+  pl.light = n_rows <= SCREEN_LIGHT_MAX_ROWS;
   pl.pre_tiles = std::min(SCREEN_PRE_TILES, pl.n_tiles / 8);
   pl.pre_slices = pl.n_slices;
   pl.pre_tps = (int)sskd::ceil_div(pl.pre_tiles, pl.n_slices);
@@ -2237,7 +2253,8 @@ int sskd_index_search_screened(const float* d_tiled, const void* d_bf16, int64_t
   switch (pl.QB) {
 #define SSKD_SCREEN_CASE(qb, bg, rg)                                                                      \
   case qb:                                                                                                \
-    kern = reinterpret_cast<const void*>(screen_append_kernel<10, qb, SCREEN_WAVES, bg, rg>);             \
+    kern = pl.light ? reinterpret_cast<const void*>(screen_append_kernel<10, qb, SCREEN_WAVES, true, bg, rg>)   \
+                    : reinterpret_cast<const void*>(screen_append_kernel<10, qb, SCREEN_WAVES, false, bg, rg>); \
     break;
     SSKD_SCREEN_CASE(2, BGROUP, SCREEN_RING)
     SSKD_SCREEN_CASE(4, BGROUP, SCREEN_RING)
