@@ -796,7 +796,7 @@ constexpr int SCREEN_MAX_CAND = 256;             // candidates re-scored per que
 // the usual case - still fills the chip), the rest to a launch planned for nq - TIER1 (only duplicate-flooded corpora
 // ever get there).  Both read their actual query count from device memory; with none, every workgroup exits at once.
 constexpr int SCREEN_FALLBACK_TIER1 = 1024;
-constexpr int64_t SCREEN_LIGHT_MAX_ROWS = 500000;   // shards up to this size keep their pools with one offer per lane and tile
+constexpr int SCREEN_LIGHT_MAX_TILES_PER_WAVE = 330;   // slices up to this length (500 k rows at 10 000 queries) keep their pools with one offer per lane and tile
 constexpr int SCREEN_CUS = 256;                  // MI355X: the launch geometry is planned in whole rounds of the chip
 
 // fp32 tiled corpus -> bf16 tiled corpus in A-operand order of v_mfma_f32_32x32x16_bf16:
@@ -2114,7 +2114,9 @@ bool screen_plan(int64_t n_rows, int nq, int k, ScreenPlan* sp) {
   pl.lists_per_query = pl.n_slices * SCREEN_WAVES * 2;
   pl.part_elems = (size_t)nq * pl.lists_per_query * pl.LK;
   // sample phase: the first SCREEN_PRE_TILES tiles (at most an eighth of the shard), cut over the slices
-  pl.light = n_rows <= SCREEN_LIGHT_MAX_ROWS;
+  // by slice length, not shard size: 1 000 queries cut 1 M rows into 32 slices of 81 tiles per wave (-7 % in the light
+  // form), 10 000 queries into 4 of 651 (+1 %)
+  pl.light = pl.tiles_per_slice <= SCREEN_LIGHT_MAX_TILES_PER_WAVE * SCREEN_WAVES;
   pl.pre_tiles = std::min(SCREEN_PRE_TILES, pl.n_tiles / 8);
   pl.pre_slices = pl.n_slices;
   pl.pre_tps = (int)sskd::ceil_div(pl.pre_tiles, pl.n_slices);
