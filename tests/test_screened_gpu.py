@@ -350,3 +350,135 @@ def test_screened_equals_exact_scan_over_random_launch_geometries(gpu, native_li
         assert int(status[0]) == 0, (n, nq, k)
         assert torch.equal(out_i, ref_i) and torch.equal(out_s, ref_s), (n, nq, k, int(status[1]))
     assert {q for q, _ in seen} == {64, 128, 160} and {d for _, d in seen} == {True, False}, seen
+
+
+# --------------------------------------------------------------------------------------------------
+# The sample phase and the main phase of slice 0 walk the same tiles.  A pruning pool that counted a row of those
+# tiles twice would hold fewer than k DISTINCT rows behind its minimum: the "lower bound" would sit above the true
+# k-th best score and prune rows of the top k silently.  These cases are built
+# from the launch plan so that it would show: neighbours inside the sample rows, the rest of the top k far behind
+# them in score (>> 2e) and late in the shard.
+# --------------------------------------------------------------------------------------------------
+def _plan(lib, n, nq, k=10):
+    qpb, passes, slices = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    _native.check(lib.sskd_index_search_screened_plan(n, nq, k, ctypes.byref(qpb), ctypes.byref(passes), ctypes.byref(slices)))
+    return qpb.value, passes.value, slices.value
+
+
+def _towards(u, cos, noise):
+    """unit rows at the given cosines to the unit vector u (noise made orthogonal to u first)"""
+    noise = noise - np.outer(noise @ u, u)
+    noise /= np.linalg.norm(noise, axis=1, keepdims=True)
+    cos = np.asarray(cos, np.float32)[:, None]
+    return (cos * u[None] + np.sqrt(1.0 - cos * cos) * noise).astype(np.float32)
+
+
+def test_screened_sample_rows_count_once_single_slice(gpu, native_lib):
+    """ONE slice (256 query blocks of 160 fill the chip): the whole sample lies inside the only slice, and the
+    kernel runs its one-offer-per-lane-and-tile form.  Nine strong neighbours (cosine 0.95 ... 0.91) sit in nine
+    different (tile, half-wave) groups of the sample rows - each is the best row of its group, so each is offered
+    in both phases - and the tenth neighbour (0.5; then 0.47, 0.44) is among the last rows of the shard."""
+    n, nq = 65536, 40960
+    qpb, _, slices = _plan(native_lib, n, nq)
+    assert (qpb, slices) == (160, 1), (qpb, slices)
+    u = oracle.seeded_unit_rows(1, 384, 61)[0]
+    corpus = oracle.seeded_unit_rows(n, 384, 62)
+    groups = [(3, 0), (9, 1), (14, 0), (20, 1), (27, 0), (33, 1), (41, 0), (50, 1), (58, 0)]   # (tile < 64, half)
+    near = [32 * t + 4 * h + 1 for t, h in groups]
+    far = [n - 37, n - 1500, n - 4001]
+    corpus[near] = _towards(u, [0.95 - 0.005 * i for i in range(9)], oracle.seeded_unit_rows(9, 384, 63))
+    corpus[far] = _towards(u, [0.5, 0.47, 0.44], oracle.seeded_unit_rows(3, 384, 64))
+    queries = oracle.seeded_unit_rows(nq, 384, 65)
+    planted = list(range(5, nq, 160))
+    queries[planted] = _towards(u, [0.999] * len(planted), queries[planted])
+    s, i, st = screened(native_lib, corpus, queries, 10)
+    sel = planted[:24] + planted[-8:] + [0, 1, 2, nq - 1]
+    ref_s, ref_i = oracle.topk_fma(queries[sel], corpus, 10)
+    assert list(ref_i[0]) == near + far[:1]
+    assert st[0] == 0
+    assert np.array_equal(i[sel], ref_i) and np.array_equal(s[sel], ref_s), (i[sel[0]], ref_i[0], int(st[1]))
+
+
+@pytest.mark.parametrize("members", [5, 7, 9])
+def test_screened_near_duplicate_cluster_from_row_zero(gpu, native_lib, members):
+    """5-9 near-duplicates of one passage in the shard's first rows (consecutive rows from row 0, and a second
+    cluster with one member per tile), the other neighbours of the top 10 much weaker and at the far end; a
+    several-slice geometry whose slice 0 still contains the sample."""
+    n, nq = 131072, 2048
+    u = oracle.seeded_unit_rows(2, 384, 71)
+    corpus = oracle.seeded_unit_rows(n, 384, 72)
+    c0 = list(range(members))                               # consecutive rows from row 0
+    c1 = [32 * (2 * t + 1) + 5 for t in range(members)]     # one per odd tile, upper half-wave
+    corpus[c0] = _towards(u[0], [0.97 - 0.004 * i for i in range(members)], oracle.seeded_unit_rows(members, 384, 73))
+    corpus[c1] = _towards(u[1], [0.96 - 0.004 * i for i in range(members)], oracle.seeded_unit_rows(members, 384, 74))
+    tail0 = [n - 100 - 977 * i for i in range(8)]
+    tail1 = [n // 2 + 31 + 1013 * i for i in range(8)]
+    corpus[tail0] = _towards(u[0], [0.55 - 0.03 * i for i in range(8)], oracle.seeded_unit_rows(8, 384, 75))
+    corpus[tail1] = _towards(u[1], [0.52 - 0.03 * i for i in range(8)], oracle.seeded_unit_rows(8, 384, 76))
+    queries = oracle.seeded_unit_rows(nq, 384, 77)
+    p0, p1 = list(range(0, nq, 16)), list(range(7, nq, 16))
+    queries[p0] = _towards(u[0], [0.999] * len(p0), queries[p0])
+    queries[p1] = _towards(u[1], [0.999] * len(p1), queries[p1])
+    s, i, st = screened(native_lib, corpus, queries, 10)
+    sel = p0[:12] + p1[:12] + [1, 2, 3]
+    ref_s, ref_i = oracle.topk_fma(queries[sel], corpus, 10)
+    assert list(ref_i[0]) == c0 + tail0[: 10 - members] and list(ref_i[12]) == c1 + tail1[: 10 - members]
+    assert st[0] == 0
+    assert np.array_equal(i[sel], ref_i) and np.array_equal(s[sel], ref_s)
+
+
+def test_screened_topic_sorted_corpus_at_the_bench_geometry(gpu, native_lib):
+    """Locality-ordered corpus at the cfg-2 shape (1 M rows x 10 000 queries: 63 blocks of 160 queries x 4 slices,
+    the every-appended-row-is-offered form): rows sorted by topic, a topic = documents of 8 adjacent chunks.  A
+    query about a document finds its 8 chunks (0.9) and then the best chunks of OTHER documents of the topic (0.6),
+    thousands of rows later.  Queries on every document of the shard's first 2 048 rows (the sample), of the rows
+    around the slice boundaries and of the last rows; the oracle's bits on those, the exact scan's on all."""
+    n, nq, per_doc, topics = 1_000_000, 10_000, 8, 64
+    qpb, _, slices = _plan(native_lib, n, nq)
+    assert (qpb, slices) == (160, 4), (qpb, slices)
+    rng = np.random.Generator(np.random.PCG64(81))
+    n_docs = n // per_doc
+    docs_per_topic = -(-n_docs // topics)
+    centres = oracle.seeded_unit_rows(topics, 384, 82)
+    topic_of_doc = np.arange(n_docs) // docs_per_topic
+    doc = 0.7 * centres[topic_of_doc] + 0.7 * oracle.seeded_unit_rows(n_docs, 384, 83)
+    doc /= np.linalg.norm(doc, axis=1, keepdims=True)
+    corpus = np.repeat(doc, per_doc, axis=0)
+    corpus *= np.float32(0.9)
+    corpus += np.float32(0.44) * oracle.seeded_unit_rows(n, 384, 84)
+    corpus /= np.linalg.norm(corpus, axis=1, keepdims=True)
+    corpus = corpus.astype(np.float32)
+    tiles_per_slice = -(-(n // 32) // slices)
+    asked = list(range(0, 2048 // per_doc))                                            # the sample rows
+    for sl in range(1, slices):
+        asked += list(range(sl * tiles_per_slice * 32 // per_doc - 4, sl * tiles_per_slice * 32 // per_doc + 4))
+    asked += list(range(n_docs - 8, n_docs))
+    queries = oracle.seeded_unit_rows(nq, 384, 85)
+    planted = [(37 * j) % nq for j in range(len(asked))]
+    assert len(set(planted)) == len(planted)
+    queries[planted] = doc[asked] + 0.1 * queries[planted]
+    queries /= np.linalg.norm(queries, axis=1, keepdims=True)
+    queries = queries.astype(np.float32)
+
+    tiled = tile_corpus(native_lib, corpus)
+    bf = torch.empty(int(native_lib.sskd_index_bf16_bytes(n)), dtype=torch.uint8, device="cuda")
+    _native.check(native_lib.sskd_index_make_bf16(tiled.data_ptr(), n, bf.data_ptr(), stream()))
+    q = torch.from_numpy(queries).cuda()
+    out_s = torch.full((nq, 10), float("nan"), device="cuda")
+    out_i = torch.full((nq, 10), -7, dtype=torch.int64, device="cuda")
+    status = torch.full((2,), -1, dtype=torch.int32, device="cuda")
+    ws = torch.empty(int(native_lib.sskd_index_search_screened_workspace_bytes(n, nq, 10)), dtype=torch.uint8, device="cuda")
+    _native.check(native_lib.sskd_index_search_screened(tiled.data_ptr(), bf.data_ptr(), n, q.data_ptr(), nq, 10, 0,
+                                                        out_s.data_ptr(), out_i.data_ptr(), status.data_ptr(), ws.data_ptr(),
+                                                        ws.numel(), stream(), None, None))
+    ex_s, ex_i = _exact(native_lib, tiled, n, q, nq, 10, 0)
+    torch.cuda.synchronize()
+    assert int(status[0]) == 0
+    ref_s, ref_i = oracle.topk_fma(queries[planted], corpus, 10)
+    own = np.array([[per_doc * d + c for c in range(per_doc)] for d in asked])
+    assert all(set(own[r]) <= set(ref_i[r]) for r in range(len(asked)))               # 8 own chunks + 2 of the topic
+    got_i, got_s = out_i.cpu().numpy(), out_s.cpu().numpy()
+    wrong = [asked[r] for r in range(len(asked)) if not (np.array_equal(got_i[planted[r]], ref_i[r])
+                                                          and np.array_equal(got_s[planted[r]], ref_s[r]))]
+    assert not wrong, ("documents whose query lost a top-10 row", wrong[:20], len(wrong))
+    assert torch.equal(out_i, ex_i) and torch.equal(out_s, ex_s)
