@@ -6,16 +6,24 @@
  * library, and only as the checker.  The product path (semantic-search-kd_amd/)
  * never links, imports or calls it.
  *
- * PARITY PINNING: the reference (Axionis47/semantic-search-kd) stores no golden
- * vectors for this path, and its engines — faiss-cpu ^1.7.4,
- * sentence-transformers ^2.2.2 (pyproject.toml:11-15) — are not installed here,
- * so the search oracle is pinned by the reference's own *semantics* only:
+ * PARITY PINNING: pinned.  The reference (Axionis47/semantic-search-kd) stores no golden
+ * vectors for this path and its engines - faiss-cpu ^1.7.4,
+ * sentence-transformers ^2.2.2 (pyproject.toml:11-15) - are not installed here, so the
+ * vectors were made by RUNNING the reference's own code in the build container
+ * (tests/golden/make_golden.py, committed with the fixtures):
+ *   - tests/golden/search_ref_{small,1k}.npz: the ids looked up by the reference's
+ *     np.argsort(scores)[::-1][:k] (src/kd/eval.py:86, scripts/simple_eval.py:25,35) inside
+ *     its own scripts/simple_eval.py::evaluate_model and KDEvaluator.evaluate_retrieval,
+ *     and the similarity matrix its np.matmul produced, on the reference's index-fixture
+ *     recipe (tests/conftest.py:65-73) and the cfg-1 shape;
+ *   - tests/test_oracle_golden.py asserts this file's search against them (ids equal
+ *     outside the one listed near-tie, scores within 1e-6; gate 1e-3).
+ * Semantics restated:
  *   - exact search idiom  top_k = np.argsort(scores)[::-1][:k]        src/kd/eval.py:86
  *   - scores = q @ corpus.T in fp32                                    scripts/simple_eval.py:25
  *   - faiss.IndexFlatIP(384).add / search on L2-normalised rows        tests/conftest.py:184-185
  *   - ids int64, -1 when fewer than k rows                             src/serve/app.py:299-301
- * "parity unpinned" for bit-level outputs; pinned for the encoder against
- * transformers.BertModel (see oracle/encoder.py).
+ * The encoder oracle is pinned against transformers.BertModel (see oracle/encoder.py).
  *
  * Floating-point order.  fp32 dot products have no canonical summation order
  * (BLAS, faiss and numpy all differ).  oracle_scores_fma() uses the order of the

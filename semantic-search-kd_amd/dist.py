@@ -141,22 +141,25 @@ class ShardedSearcher:
         if i.data_ptr() != out_i.data_ptr():
             out_i.copy_(i)
 
-    def search(self, queries: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
-        import torch.distributed as dist
-
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
-            self.last_world = 1
-            return self.local_search(queries, k)
-        world = dist.get_world_size(self.group)
-        self.last_world = world
+    def search_local(self, queries: torch.Tensor, k: int) -> torch.Tensor:
+        """This rank's half of a sharded search, no communication: the local scan writes its ``(scores, GLOBAL
+        ids)`` straight into a fresh packed record, which is returned (``gather_merge`` takes it from there).
+        Split from ``search`` so that a caller can agree with the other ranks that every local scan succeeded
+        BEFORE any rank enters the device collective (sharded_index.ShardedIndex)."""
         nq = queries.shape[0]
-        rec = record_bytes(nq, k)
-        if rec == 0:
-            return self.local_search(queries, k)
-        dev = queries.device
-        send = torch.empty(rec, dtype=torch.uint8, device=dev)
+        send = torch.empty(record_bytes(nq, k), dtype=torch.uint8, device=queries.device)
         out_s, out_i = record_views(send, nq, k)
         self._local_into(queries, k, out_s, out_i)
+        return send
+
+    def gather_merge(self, send: torch.Tensor, nq: int, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """ONE all-gather of the packed records (RCCL over xGMI on a GPU node) and the merge of the G lists."""
+        import torch.distributed as dist
+
+        world = dist.get_world_size(self.group)
+        self.last_world = world
+        rec = record_bytes(nq, k)
+        dev = send.device
         recv = torch.empty(world * rec, dtype=torch.uint8, device=dev)
         if self.all_gather is not None:
             self.all_gather(recv, send)
@@ -175,3 +178,14 @@ class ShardedSearcher:
             all_s = table[:, nq * k * 8 : nq * k * 12].contiguous().view(torch.float32).view(world, nq, k)
             return self.merge(all_s, all_i, k)
         return hip_merge_packed(recv, world, nq, k, k)
+
+    def search(self, queries: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            self.last_world = 1
+            return self.local_search(queries, k)
+        nq = queries.shape[0]
+        if record_bytes(nq, k) == 0:
+            return self.local_search(queries, k)
+        return self.gather_merge(self.search_local(queries, k), nq, k)

@@ -155,7 +155,9 @@ def register_routes(app: FastAPI, settings: ServeSettings) -> None:
         return HealthResponse(
             status="healthy" if app_state.is_ready() else "unhealthy",
             model_loaded=app_state.student is not None,
-            index_loaded=app_state.index_builder is not None,
+            # a row-sharded index counts as loaded only while EVERY rank holds its shards and answers
+            # (sharded_index.ShardedIndex.is_loaded)
+            index_loaded=app_state.index_builder is not None and bool(getattr(app_state.index_builder, "is_loaded", True)),
             index_size=len(app_state.doc_ids) if app_state.doc_ids else 0,
             version=VERSION,
         )

@@ -12,6 +12,7 @@ of the same directory (all shards on one GPU).
 from __future__ import annotations
 
 import argparse
+import datetime
 import os
 import sys
 
@@ -30,10 +31,14 @@ def init_group_from_env() -> tuple:
     device = f"cuda:{local_rank}" if one_gpu_each else "cuda:0"
     torch.cuda.set_device(torch.device(device))
     if not dist.is_initialized():
+        # The DATA group's timeout bounds one search (query broadcast + all-gather, entered only after every rank
+        # has reported a successful local scan).  Idle ranks do not wait in it: they park in a host broadcast on
+        # ShardedIndex's gloo control group, which no watchdog aborts (sharded_index.py, "Failure path").
+        timeout = datetime.timedelta(seconds=float(os.environ.get("SEMANTIC_KD_SHARD_OP_TIMEOUT_S", "120")))
         if one_gpu_each:
-            dist.init_process_group("nccl", device_id=torch.device(device))   # RCCL over xGMI
+            dist.init_process_group("nccl", device_id=torch.device(device), timeout=timeout)   # RCCL over xGMI
         else:
-            dist.init_process_group("gloo")                                   # rehearsal: ranks share a GPU
+            dist.init_process_group("gloo", timeout=timeout)                  # rehearsal: ranks share a GPU
     return world, dist.get_rank(), device
 
 
@@ -50,8 +55,14 @@ def main(argv=None) -> int:
     ap.add_argument("--port", type=int, default=8000)
     args = ap.parse_args(argv)
     world, rank, device = init_group_from_env()
-    index = ShardedIndex(device=device)
-    index.load_all_ranks(args.index_dir)
+    index = ShardedIndex(device=device, op_timeout_s=float(os.environ.get("SEMANTIC_KD_SHARD_OP_TIMEOUT_S", "120")))
+    try:
+        index.load_all_ranks(args.index_dir)   # ShardFailure on EVERY rank when any rank cannot load its shards
+    except Exception as exc:  # noqa: BLE001
+        print(f"[rank {rank}] cannot serve {args.index_dir}: {exc}", file=sys.stderr, flush=True)
+        if world > 1 and dist.is_initialized():
+            dist.destroy_process_group()
+        return 1
     try:
         if rank != 0:
             index.serve_forever()

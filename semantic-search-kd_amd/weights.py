@@ -70,7 +70,8 @@ def synthetic_tensor(name: str, shape, scale: float) -> np.ndarray:
 STRESS_OUTLIER_CHANNELS = (7, 133, 300)
 
 
-def synthetic_state_dict(cfg: BertConfig, nonzero_bias: bool = True, stress: bool = False) -> Dict[str, np.ndarray]:
+def synthetic_state_dict(cfg: BertConfig, nonzero_bias: bool = True, stress: bool = False,
+                         recipe: str = "init") -> Dict[str, np.ndarray]:
     """fp32 state dict with HF ``BertModel`` parameter names (no pooler: mean pooling ignores it).
 
     ``nonzero_bias`` also draws biases / LayerNorm parameters (small, around their defaults) so
@@ -81,11 +82,26 @@ def synthetic_state_dict(cfg: BertConfig, nonzero_bias: bool = True, stress: boo
     the online-softmax rescale and bf16 P.V paths matter), LayerNorm gains log-uniform in
     [0.3, 3], biases of +-0.5, and three outlier channels whose LayerNorm bias is +-10 (the
     near-constant massive-activation channels real BERT checkpoints have: 10x the typical value).
+
+    ``recipe="spread"`` draws weights with the GAINS of a trained checkpoint instead of the 0.02 init (which barely
+    mixes tokens: embeddings of different texts then lie within 1e-3 cosine of each other and no test on them can
+    tell a wrong row from rounding): unit-variance word embeddings (token identity dominates position), every
+    projection at unit gain (sqrt(3 / fan_in) uniform), query / key at 1.4x so that attention logits are O(2).
+    Embeddings of different texts then separate by O(0.1 ... 1) in cosine.
     """
+    if recipe not in ("init", "spread"):
+        raise ValueError(f"unknown weight recipe {recipe!r}")
     h, f = cfg.hidden_size, cfg.intermediate_size
     w_scale = 0.02 * np.sqrt(3.0)
 
     def mat(name, shape):
+        if recipe == "spread":
+            if name.endswith("word_embeddings.weight"):
+                return synthetic_tensor(name, shape, float(np.sqrt(3.0)))
+            if "embeddings." in name and "encoder." not in name:
+                return synthetic_tensor(name, shape, 0.1 * float(np.sqrt(3.0)))
+            gain = 1.4 if (".query." in name or ".key." in name) else 1.0
+            return synthetic_tensor(name, shape, gain * float(np.sqrt(3.0 / shape[1])))
         w = synthetic_tensor(name, shape, w_scale)
         if stress and (".query." in name or ".key." in name):
             w = w * np.float32(3.5)

@@ -110,6 +110,24 @@ def test_search_glue_semantics(client):
     assert r.status_code == 500 and r.json()["error"] == "Search failed: HIP error"
 
 
+def test_sharded_failure_is_a_500_and_health_reflects_shard_state(client):
+    """reference: src/serve/app.py:354-361; SURVEY.md section 5 - a failed rank of a sharded index surfaces as the
+    route's 500, and /health.index_loaded follows the shards' state, not the mere existence of rank 0's object."""
+    from semantic_search_kd_amd.sharded_index import ShardedIndex, ShardFailure
+
+    index = ShardedIndex()
+    app_state.index_builder, app_state.doc_ids = index, ["a", "b"]
+    assert client.get("/health").json()["index_loaded"] is False          # nothing loaded on the ranks yet
+    index.local = object()
+    assert client.get("/health").json()["index_loaded"] is True
+    index.search = MagicMock(side_effect=ShardFailure("search", {3: "RuntimeError: HIP error: out of memory"}))
+    r = client.post("/search", json={"query": "q"})
+    assert r.status_code == 500 and "rank 3" in r.json()["error"] and r.json()["error"].startswith("Search failed:")
+    index.broken = "search: a rank did not report within 60 s"
+    assert client.get("/health").json()["index_loaded"] is False
+    assert index.health()["loaded"] is False and index.health()["broken"]
+
+
 def test_index_load_missing_dir_is_404(client):
     r = client.post("/index/load", params={"index_path": "/nonexistent/dir"})
     assert r.status_code == 404 and "Index not found" in r.json()["error"]

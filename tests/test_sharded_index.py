@@ -23,7 +23,7 @@ import torch.multiprocessing as mp
 from oracle import search as oracle
 from semantic_search_kd_amd.dist import shard_bounds
 from semantic_search_kd_amd.index import read_flat_ip, write_flat_ip
-from semantic_search_kd_amd.sharded_index import MANIFEST, ShardedIndex, build_sharded, open_index
+from semantic_search_kd_amd.sharded_index import MANIFEST, ShardedIndex, ShardFailure, build_sharded, open_index
 
 N_DOCS = 203
 
@@ -124,14 +124,14 @@ def _serve_worker(rank, world, port, tmp, index_dir, second_dir):
         index = ShardedIndex(index_factory=_factory)
         index.load_all_ranks(index_dir)
         index._searcher.merge = _oracle_merge
+        orig_commit = index._commit
+
+        def commit(staged):   # a reload builds a new searcher: give it the CPU merge again
+            orig_commit(staged)
+            index._searcher.merge = _oracle_merge
+
+        index._commit = commit
         if rank != 0:
-            orig = index._load_local
-
-            def reload(d):   # the reload announced by rank 0 builds a new searcher: give it the CPU merge again
-                orig(d)
-                index._searcher.merge = _oracle_merge
-
-            index._load_local = reload
             index.serve_forever()
             return
         ref_s, ref_i = oracle.topk_fma(_queries(), _ROWS, 10)
@@ -190,6 +190,170 @@ def test_more_ranks_than_shards_and_open_index_dispatch(tmp_path):
     assert is_sharded_dir(d2) and not is_sharded_dir(d2 / "shard_0")
     cur = ShardedIndex(index_factory=_factory)
     assert open_index(d2, 384, current=cur) is cur and cur.ntotal == N_DOCS
+
+
+# ----------------------------------------------------------------------------- failure path
+class FlakyIndex(OracleIndex):
+    """OracleIndex whose search_device raises while the file <tmp>/fail_search_rank<r> exists (removed on use)"""
+
+    tmp = None
+
+    def search_device(self, q, k, normalize_queries=None, out_scores=None, out_ids=None):
+        flag = Path(FlakyIndex.tmp) / f"fail_search_rank{dist.get_rank()}"
+        if flag.exists():
+            flag.unlink()
+            raise RuntimeError("HIP error: injected scan failure")
+        return super().search_device(q, k, normalize_queries, out_scores, out_ids)
+
+
+def _flaky_factory(embedding_dim, metric, device, id_offset):
+    return FlakyIndex(embedding_dim, metric, device, id_offset)
+
+
+def _failing_worker(rank, world, port, tmp, good_dir, bad_dir):
+    import time
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    FlakyIndex.tmp = tmp
+    try:
+        index = ShardedIndex(index_factory=_flaky_factory, op_timeout_s=30.0)
+        index.load_all_ranks(good_dir)
+        orig_commit = index._commit
+
+        def commit(staged):   # every (re)load builds a new searcher: give it the CPU merge again
+            orig_commit(staged)
+            index._searcher.merge = _oracle_merge
+
+        index._commit = commit
+        index._searcher.merge = _oracle_merge
+        if rank != 0:
+            index.serve_forever()
+            return
+        ref_s, ref_i = oracle.topk_fma(_queries(), _ROWS, 10)
+        s, i = index.search(_queries(), 10)
+        assert np.array_equal(i, ref_i) and index.is_loaded
+        # (1) a call that is wrong in itself never reaches the other ranks: plain ValueError, deployment untouched
+        with pytest.raises(ValueError):
+            index.search(np.zeros((3, 100), np.float32), 10)
+        with pytest.raises(ValueError):
+            index.search(_queries(), 0)
+        # (2) rank 1's scan raises: rank 0 gets ShardFailure naming rank 1, promptly; the next request works
+        (Path(tmp) / "fail_search_rank1").write_text("x")
+        t0 = time.time()
+        with pytest.raises(ShardFailure) as err:
+            index.search(_queries(), 10)
+        assert time.time() - t0 < 20 and list(err.value.failures) == [1] and "injected scan failure" in str(err.value)
+        assert index.is_loaded and index.last_failure == err.value.failures
+        s, i = index.search(_queries(), 10)
+        assert np.array_equal(i, ref_i) and np.array_equal(s, ref_s) and index.last_failure is None
+        # ... and rank 0's own scan
+        (Path(tmp) / "fail_search_rank0").write_text("x")
+        with pytest.raises(ShardFailure) as err:
+            index.search(_queries(), 10)
+        assert list(err.value.failures) == [0]
+        # (3) a reload that one rank cannot do (shard_1/ is missing): ShardFailure, and EVERY rank keeps serving the
+        # index it had
+        t0 = time.time()
+        with pytest.raises(ShardFailure) as err:
+            index.load(bad_dir)
+        assert time.time() - t0 < 20 and 1 in err.value.failures and index.is_loaded
+        assert index.ntotal == N_DOCS and index.health()["last_failure"] == err.value.failures
+        s, i = index.search(_queries(), 10)
+        assert np.array_equal(i, ref_i) and np.array_equal(s, ref_s)
+        # (4) a directory rank 0 cannot even read is refused before anything is announced
+        with pytest.raises(FileNotFoundError):
+            index.load(Path(tmp) / "nowhere")
+        s, i = index.search(_queries()[:2], 5)
+        assert np.array_equal(i, ref_i[:2, :5])
+        index.load(good_dir)                      # and a good reload still works afterwards
+        s, i = index.search(_queries(), 10)
+        assert np.array_equal(i, ref_i)
+        index.close()
+        (Path(tmp) / "failure_path_ok").write_text("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_serve_fails_loudly_and_keeps_serving(tmp_path):
+    """reference: src/serve/app.py:354-361 (any exception -> 500), SURVEY.md section 5.  A rank whose scan raises and a
+    rank that cannot load its shard both surface on rank 0 as ShardFailure within the timeout - nobody is left
+    blocked in a collective - and the next request is answered."""
+    import shutil
+
+    _corpus(tmp_path)
+    mp.spawn(_build_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    good = tmp_path / "index_w2"
+    bad = tmp_path / "index_bad"
+    shutil.copytree(good, bad)
+    shutil.rmtree(bad / "shard_1")
+    (bad / "shard_1").mkdir()                    # present but empty: rank 1's load raises, rank 0's does not...
+    shutil.copy(good / "shard_1" / "doc_ids.json", bad / "shard_1" / "doc_ids.json")   # (rank 0 reads only the id lists)
+    shutil.copy(good / "shard_1" / "texts.json", bad / "shard_1" / "texts.json")
+    mp.spawn(_failing_worker, args=(2, _free_port(), str(tmp_path), str(good), str(bad)), nprocs=2, join=True)
+    assert (tmp_path / "failure_path_ok").exists()
+
+
+def _dead_rank_worker(rank, world, port, tmp, good_dir):
+    import time
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    index = ShardedIndex(index_factory=_factory, op_timeout_s=5.0)
+    index.load_all_ranks(good_dir)
+    index._searcher.merge = _oracle_merge
+    if rank != 0:
+        os._exit(0)                               # the rank dies without a word
+    time.sleep(1.0)
+    t0 = time.time()
+    try:
+        index.search(_queries(), 10)
+        raise AssertionError("a search with a dead rank must not succeed")
+    except AssertionError:
+        raise
+    except Exception as exc:  # noqa: BLE001 - ShardFailure, or the backend's own connection error
+        took = time.time() - t0
+        assert took < 30, took
+        (Path(tmp) / "dead_rank_seen").write_text(f"{type(exc).__name__} after {took:.1f}s")
+    if index.broken is not None:                  # timed out in the status exchange: later calls fail fast
+        assert not index.is_loaded
+        t0 = time.time()
+        with pytest.raises(ShardFailure):
+            index.search(_queries(), 10)
+        assert time.time() - t0 < 1.0
+    os._exit(0)                                   # (no clean shutdown of a group whose peer is gone)
+
+
+def test_sharded_serve_notices_a_dead_rank(tmp_path):
+    _corpus(tmp_path)
+    mp.spawn(_build_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_dead_rank_worker, args=(2, _free_port(), str(tmp_path), str(tmp_path / "index_w2")), nprocs=2, join=True)
+    assert (tmp_path / "dead_rank_seen").exists()
+
+
+def _startup_failure_worker(rank, world, port, tmp, bad_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        index = ShardedIndex(index_factory=_factory, op_timeout_s=30.0)
+        with pytest.raises(ShardFailure) as err:    # EVERY rank raises: the launcher exits instead of hanging
+            index.load_all_ranks(bad_dir)
+        assert 1 in err.value.failures and not index.is_loaded
+        (Path(tmp) / f"startup_failure_rank{rank}").write_text("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_startup_fails_on_every_rank(tmp_path):
+    import shutil
+
+    _corpus(tmp_path)
+    mp.spawn(_build_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    bad = tmp_path / "index_bad"
+    shutil.copytree(tmp_path / "index_w2", bad)
+    (bad / "shard_1" / "index.faiss").unlink()
+    mp.spawn(_startup_failure_worker, args=(2, _free_port(), str(tmp_path), str(bad)), nprocs=2, join=True)
+    assert all((tmp_path / f"startup_failure_rank{r}").exists() for r in range(2))
 
 
 # ----------------------------------------------------------------------------- GPU: the real shards
@@ -265,11 +429,18 @@ def test_build_index_cli_under_torchrun_two_ranks(gpu, tmp_path):
     vocab = _vocab()
     cfg = BertConfig(vocab_size=len(vocab), num_hidden_layers=2)
     mdir = tmp_path / "model"
-    save_model_dir(mdir, cfg, synthetic_state_dict(cfg))
+    # weights with trained-like gains: the 41 passages separate by O(0.1) in cosine (under the 0.02 init they lie
+    # within 1e-3 of each other and only set membership could be asserted - VERDICT r3 weak 3)
+    save_model_dir(mdir, cfg, synthetic_state_dict(cfg, recipe="spread"))
     (mdir / "vocab.txt").write_text("\n".join(vocab))
-    docs = [" ".join(vocab[5 + (i * 7 + j) % (len(vocab) - 5)] for j in range(3 + i % 9)) for i in range(41)]
+    # whole words of the vocabulary only (round 3 drew from ALL entries: "[unused7]" and "##s" tokenise to runs of
+    # [UNK], so most passages were the same token sequence up to its length)
+    plain = [w for w in vocab[104:] if w.isalpha()]
+    docs = [" ".join(plain[(i * 7 + j * 3) % len(plain)] for j in range(3 + i % 9)) for i in range(41)]
+    assert len(set(docs)) == 41
     corpus = tmp_path / "c.parquet"
-    pd.DataFrame({"chunk_id": [f"c{i}" for i in range(len(docs))], "text": docs}).to_parquet(corpus)
+    ids = [f"c{i}" for i in range(len(docs))]
+    pd.DataFrame({"chunk_id": ids, "text": docs}).to_parquet(corpus)
     out = tmp_path / "idx"
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=str(Path(__file__).resolve().parent.parent))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
@@ -281,14 +452,32 @@ def test_build_index_cli_under_torchrun_two_ranks(gpu, tmp_path):
     student = StudentModel(str(mdir), device="cuda:0")
     whole = FAISSIndexBuilder(embedding_dim=384, metric="cosine", device="cuda:0")
     whole.build_from_parquet(model=student, parquet_path=corpus, batch_size=8)
+    # the passages ARE separated: the best other passage trails a passage's own embedding by far more than the 2e-3
+    # a different launch composition can move a score
     sharded = open_index(out, 384, device="cuda:0")
     assert isinstance(sharded, ShardedIndex) and sharded.doc_ids == whole.doc_ids and sharded.ntotal == 41
     q = student.encode_queries([docs[3], docs[17], "zzz"])
     s1, i1 = sharded.search(q, 5)
     s2, i2 = whole.search(q, 5)
-    # the two builds encode a passage in different launches (different batch-mates): scores agree to bf16-encoder
-    # tolerance, and ids wherever the ranking is not a near-tie
+    print("top-5 scores, sharded build:", s1.tolist(), "single-process build:", s2.tolist())
+    assert (s2[:2, 0] - s2[:2, 1] > 0.02).all(), s2      # discriminating: top-1 leads by >> rounding
     assert np.abs(s1 - s2).max() <= 4e-3
-    for row in range(3):   # a random-init encoder puts several passages within 1e-3 of each other: compare as sets
-        assert i1[row, 0] in i2[row] and i2[row, 0] in i1[row], (i1[row], i2[row])
-    assert 3 in i1[0] and 17 in i1[1]
+    assert (i1[:, 0] == i2[:, 0]).all() and i1[0, 0] == 3 and i1[1, 0] == 17, (i1, i2)
+    gaps = s2[:, :-1] - s2[:, 1:]
+    clear = gaps > 8e-3                                   # ranks whose order a 4e-3 score shift cannot swap
+    assert (i1[:, :-1][clear] == i2[:, :-1][clear]).all(), (i1, i2, gaps)
+    # A shard holds exactly what a single-process build of ITS row range holds, bit for bit (same texts in the same
+    # launch composition): a wrong id_offset, a row dropped at a shard boundary or a shard encoded with other
+    # weights cannot hide behind a tolerance.
+    for rank in range(2):
+        lo, hi = shard_bounds(41, 2, rank)
+        part = tmp_path / f"part{rank}.parquet"
+        pd.DataFrame({"chunk_id": ids[lo:hi], "text": docs[lo:hi]}).to_parquet(part)
+        alone = FAISSIndexBuilder(embedding_dim=384, metric="cosine", device="cuda:0")
+        alone.build_from_parquet(model=student, parquet_path=part, batch_size=8)
+        alone.save(tmp_path / f"alone{rank}")
+        a = np.array(read_flat_ip(tmp_path / f"alone{rank}" / "index.faiss"))
+        b = np.array(read_flat_ip(out / f"shard_{rank}" / "index.faiss"))
+        assert a.shape == (hi - lo, 384) and np.array_equal(a, b), (rank, np.abs(a - b).max())
+        meta = json.loads((out / f"shard_{rank}" / "shard.json").read_text())
+        assert meta["id_offset"] == lo and json.loads((out / f"shard_{rank}" / "doc_ids.json").read_text()) == ids[lo:hi]
