@@ -441,6 +441,11 @@ struct MlpParams {
 };
 
 constexpr int MLP_CHUNKS = FF / 32;  // 48
+
+__device__ inline void glds16(const void* g, void* l) {   // LDS-DMA: 16 B per lane, global -> LDS, no registers
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
 #ifndef SSKD_MLP_PF
 #define SSKD_MLP_PF 6
 #endif
@@ -563,12 +568,24 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
     // slower too: v_pk_* is no bargain on these in-order waves.)  W1 chunk it+1 -> buffer (it+1) & 1 (tenant
     // it-1, last read in the burst of it-1; first read in this iteration's phase 2); W2 chunk it
     // -> buffer it & 1 (tenant it-2, read by the consumers' burst of it-1; first read in it+1).
+#ifdef SSKD_MLP_DMA
+    // EXPERIMENT: weights by LDS-DMA, 6 pieces per wave and chunk, issued at the START of each role's vector phase:
+    // the producers move W1 chunk it + 2 into the buffer their burst has just left (1.5 iterations of flight time),
+    // the consumers W2 chunk it into the buffer their previous burst left
+    auto dma_w1 = [&](int chunk, int buf) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        glds16(p.w1 + (int64_t)chunk * WTILE_VEC + (wave + 4 * i) * 64 + lane, w1buf[buf] + (wave + 4 * i) * 64);
+    };
+    dma_w1(1, 1);
+#else
     bf16x8 st1[6], st2[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       st1[i] = p.w1[WTILE_VEC + tid + 256 * i];
       st2[i] = p.w2c[tid + 256 * i];
     }
+#endif
     for (int it = 0; it <= MLP_CHUNKS; ++it) {
       SSKD_STAMP(0, it, 0);
       // ---- phase 1: MFMA burst ----
@@ -585,14 +602,29 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
         for (int s = 0; s < KSTEPS; ++s) {
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s % RING], x[s], acc, 0, 0, 0);
           if (s + PF < KSTEPS) a[(s + PF) % RING] = wl[(s + PF) * 64];
+          // Round-4 measurements of this staging traffic (same-box A/B, whole 12-layer step 6.76 / 6.84 / 6.90 ms on the
+          // three boxes used): without the 12 global loads 6.45 ms (-4.6 %), without loads AND LDS stores 5.64 ms (-16.6 % =
+          // 93 us per layer: the 48 KiB per chunk through ds_write_b128 are the kernel's largest overhead); the same bytes by
+          // LDS-DMA, six pieces per wave and chunk issued at the start of each role's vector phase with counted vmcnt
+          // (-DSSKD_MLP_DMA, bit-identical results): 7.36 vs 6.90 ms (+6.8 %: a DMA piece costs its wave more issue time
+          // than {load, ds_write_b128}); the W2 half moved to the producers' vector phase (-DSSKD_MLP_W2_IN_P2): +2.9 %;
+          // the bias as the first MFMA's C operand: +0.7 %; a 5-VALU GELU (pre-scaled weights): -0.4 %.
+#if !defined(SSKD_MLP_ABL_NOSTAGE) && !defined(SSKD_MLP_DMA)   // timing ablations (tools/ab_build.py): results wrong
           if (s % 4 == 1) {
             d1[256 * (s / 4)] = st1[s / 4];
+#ifndef SSKD_MLP_ABL_NOSTAGE_LOADS
             st1[s / 4] = s1[256 * (s / 4)];
+#endif
           }
+#ifndef SSKD_MLP_W2_IN_P2
           if (s % 4 == 3) {
             d2[256 * (s / 4)] = st2[s / 4];
+#ifndef SSKD_MLP_ABL_NOSTAGE_LOADS
             st2[s / 4] = s2[256 * (s / 4)];
+#endif
           }
+#endif
+#endif
           __builtin_amdgcn_sched_barrier(0);  // keep the reads PF slots ahead of their use
         }
         __builtin_amdgcn_s_setprio(0);
@@ -601,6 +633,9 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
       SSKD_STAMP(0, it, 1);
       __syncthreads();
       SSKD_STAMP(0, it, 2);
+#ifdef SSKD_MLP_DMA
+      if (it + 2 < MLP_CHUNKS) dma_w1(it + 2, it & 1);
+#endif
       // ---- phase 2: vector work while the consumer multiplies ----
       {
         const int c = it < MLP_CHUNKS ? it : MLP_CHUNKS - 1;
@@ -627,8 +662,24 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
           pk[1] = (__bf16)gelu_erf(pre[1]);
           reinterpret_cast<bf16x2*>(&hdone[tg][g >> 1][dl])[h] = pk;
         }
+#ifdef SSKD_MLP_W2_IN_P2
+        {   // EXPERIMENT: the W2 half of the staging in the vector phase (W2 chunk it -> buffer it & 1, read from it + 1 on)
+          bf16x8* const d2 = w2buf[it & 1] + tid;
+          const bf16x8* const s2 = p.w2c + (int64_t)(it + 1 < MLP_CHUNKS ? it + 1 : MLP_CHUNKS - 1) * WTILE_VEC + tid;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            d2[256 * i] = st2[i];
+            st2[i] = s2[256 * i];
+          }
+        }
+#endif
       }
       SSKD_STAMP(0, it, 3);
+#ifdef SSKD_MLP_DMA
+      // W1 chunk it + 1 (requested one iteration ago) has landed; the six pieces of chunk it + 2 may stay in flight
+      if (it + 2 < MLP_CHUNKS) __builtin_amdgcn_s_waitcnt(0x0F76);
+      else __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
       __syncthreads();
     }
   } else {
@@ -653,6 +704,13 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
     constexpr int CR = 5;  // fragment ring of the burst, in output tiles (reads run CR - 1 tiles ahead)
     for (int it = 0; it <= MLP_CHUNKS; ++it) {
       SSKD_STAMP(1, it, 0);
+#ifdef SSKD_MLP_DMA
+      if (it < MLP_CHUNKS) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+          glds16(p.w2c + (int64_t)it * WTILE_VEC + (tg + 4 * i) * 64 + lane, w2buf[it & 1] + (tg + 4 * i) * 64);
+      }
+#endif
       // ---- phase 1: vector work while the producer multiplies ----
       bf16x8 hf0, hf1;
       bf16x8 a[CR][2];
@@ -686,6 +744,11 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
         }
       }
       SSKD_STAMP(1, it, 1);
+#ifdef SSKD_MLP_DMA
+      // W2 chunk it - 1 (requested one iteration ago) has landed; the six pieces of chunk it may stay in flight
+      if (it < MLP_CHUNKS) __builtin_amdgcn_s_waitcnt(0x0F76);
+      else __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
       __syncthreads();
       SSKD_STAMP(1, it, 2);
       // ---- phase 2: MFMA burst, 12 output tiles x 2 k-steps ----
@@ -1087,6 +1150,9 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(QkvAttnParams p) {
     __syncthreads();  // step k-1 complete: weights free, K / V of head k-1 complete
     SSKD_QA_STAMP(k, 1);
     if (has_p1) {
+#ifdef SSKD_QA_ABL_NOHANDOVER   // timing ablation: only the first head's weights ever reach LDS (results wrong)
+      if (k == 0)
+#endif
 #pragma unroll
       for (int i = 0; i < 9; ++i) wlds[tid + 512 * i] = wstage[i];
       if (tid < 96) bias_lds[96 * (k & 1) + tid] = p.bqkv[(tid >> 5) * H + (head0 + k) * DH + (tid & 31)];
@@ -1094,7 +1160,9 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(QkvAttnParams p) {
     SSKD_QA_STAMP(k, 2);
     __syncthreads();
     SSKD_QA_STAMP(k, 3);
+#ifndef SSKD_QA_ABL_NOLOADS
     if (k + 1 < p.hpw) load_weights(head0 + k + 1);
+#endif
     SSKD_QA_STAMP(k, 4);
     if (TWO_TILES) {
       // S > 256: double-buffered K / V would not fit LDS -> plain schedule, one buffer

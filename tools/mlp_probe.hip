@@ -30,7 +30,7 @@ int main() {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 3; ++rep) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL(fused_mlp_ln_kernel, dim3(T / 128), dim3(512), 0, 0, m);
+    hipLaunchKernelGGL(fused_mlp_ln_kernel<false>, dim3(T / 128), dim3(512), 0, 0, m);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("launch %d: %.1f us (%s)\n", rep, ms * 1e3, hipGetErrorString(hipGetLastError()));
