@@ -129,7 +129,7 @@ int sskd_index_search_profiled(const float* d_tiled, int64_t n_rows,
  * (16x the fp32 matrix rate) over a bf16 copy of the index, then exact fp32 re-scoring of the
  * candidates inside a PROVED error band, so scores and ids are bit-identical to sskd_index_search's.
  * The band is measured, not assumed: |screen - exact| <= |q~ - q| max|row~| + |q| max|row~ - row| +
- * 1e-4 |q| max|row| (Cauchy-Schwarz on the two bf16 roundings + fp32 accumulation slack), with the
+ * 1e-4 |q| max(max|row|, max|row~|) (Cauchy-Schwarz on the two bf16 roundings + fp32 accumulation slack), with the
  * query norms taken per query and the row maxima when the sidecar is made; in the worst case (every
  * element on a bf16 tie) that is 2^-7 (1 + 2^-9) |q| max|row|, on random data about 0.42 of it.
  * The bf16 copy holds the rows MINUS their mean row (q.mean is the same for every row of a query, so
@@ -137,7 +137,10 @@ int sskd_index_search_profiled(const float* d_tiled, int64_t n_rows,
  * and with them the band, are 2-2.2x smaller.
  * Every row whose screen score reaches the running bound (a lower bound of the query's k-th best screen
  * score, minus the band) is appended to a per-lane run in the workspace, so the appended set always holds
- * the whole band; a query is answered by the exact scan inside the same call only when its band holds
+ * the whole band.  The bound is the minimum of a full pool of K scores of DISTINCT rows: a workgroup whose
+ * share of the sample phase lies inside its own slice (slice 0) empties its pool between the two phases, because
+ * the same rows are offered again there (round 3 did not, and a row counted twice could lift the bound above
+ * the true k-th best score: fixed in round 4, tests/test_screened_gpu.py "count_once" / "topic_sorted").  A query is answered by the exact scan inside the same call only when its band holds
  * more than 256 rows (hundreds of near-duplicates of its neighbours) or one run overflowed (> 64 band rows
  * in one lane's share of a slice) - the in-call fallback is sized for every query, so no output row is
  * ever unproven and callers have nothing to check.  d_status (device int[2]): [0] = always 0 (kept for ABI
