@@ -120,6 +120,7 @@ class CombinedKDLoss(nn.Module):
         self.temperature_start = temperature_start
         self.temperature_end = temperature_end
         self.current_temperature = temperature_start
+        self.component_tensors = False   # True: the three component losses come back as 0-dim device tensors (no host sync)
         self.margin_mse_loss = MarginMSELoss(temperature=temperature_start)
         self.listwise_kd_loss = ListwiseKDLoss(temperature=temperature_start)
         self.contrastive_loss = ContrastiveLoss(temperature=CONTRASTIVE_TEMPERATURE)
@@ -142,7 +143,12 @@ class CombinedKDLoss(nn.Module):
             student_scores, teacher_scores, self.margin_mse_loss.temperature, self.contrastive_loss.temperature,
             self.margin_mse_weight, self.listwise_kd_weight, self.contrastive_weight,
         )
-        mm, lk, c = (float(v) for v in comps.tolist())  # the reference returns .item() floats here too
+        if self.component_tensors or torch.cuda.is_current_stream_capturing():
+            # no host read: inside a HIP-graph capture (training.GraphedStep) a device-to-host copy is not permitted, and
+            # in an eager step it is a synchronisation point between the forward and the backward pass
+            mm, lk, c = comps[0], comps[1], comps[2]
+        else:
+            mm, lk, c = (float(v) for v in comps.tolist())  # the reference returns .item() floats here too
         return {
             "loss": total,
             "margin_mse": mm,

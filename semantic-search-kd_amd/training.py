@@ -35,6 +35,7 @@ class _EncoderFunction(torch.autograd.Function):
     def forward(ctx, module: "TrainableEncoder", ids: torch.Tensor, mask: torch.Tensor, normalize: bool, *params):
         lib = _native.load()
         B, S = ids.shape
+        module._check_autograd_contract()
         module._refresh_device_weights()
         need = int(lib.sskd_generic_workspace_bytes(module.cfg_struct, B, S, 1))
         ws = torch.empty(max(need, 1), dtype=torch.uint8, device=ids.device)
@@ -54,7 +55,14 @@ class _EncoderFunction(torch.autograd.Function):
         buffer that is zeroed with one memset when the gradients were ``None`` - and hands autograd ``None`` for them:
         no per-call set of ~150 zero-filled buffers (90 MB for e5-small, the dense 30522 x 384 word-embedding gradient
         included) and no ~150 accumulation kernels when a step calls the encoder more than once (the reference calls
-        ``encode_with_gradients`` 2 x batch_size times per step, src/kd/train.py:176-210)."""
+        ``encode_with_gradients`` 2 x batch_size times per step, src/kd/train.py:176-210).
+
+        RESTRICTION (checked in ``TrainableEncoder._check_autograd_contract``, which raises instead of returning wrong
+        gradients): this is ``loss.backward()`` semantics only.  Parameter gradients are side effects on ``p.grad``, so
+        ``torch.autograd.grad(..., params)``, ``backward(inputs=...)``, tensor / post-accumulate hooks on a parameter
+        (DDP registers those) and ``requires_grad=False`` on a single parameter are NOT served - the forward refuses
+        parameters that carry hooks or are frozen.  Data parallelism reduces the FLAT gradient buffer instead
+        (``TrainableEncoder.flat_grad``: one all-reduce of one tensor)."""
         lib = _native.load()
         module: TrainableEncoder = ctx.module
         ids, mask = ctx.saved_tensors
@@ -151,6 +159,27 @@ class TrainableEncoder(nn.Module):
 
     def p(self, hf_name: str) -> nn.Parameter:
         return getattr(self, _pname(hf_name))
+
+    @property
+    def flat_grad(self) -> torch.Tensor:
+        """every parameter's gradient in ONE fp32 tensor (the buffer all ``p.grad`` are views of): what a data-parallel
+        trainer all-reduces after ``backward()`` - the backward writes gradients as side effects, so autograd hooks
+        (DDP's mechanism) never fire"""
+        return self._flat_grad
+
+    def _check_autograd_contract(self) -> None:
+        """The HIP backward hands autograd ``None`` for every parameter and writes ``p.grad`` itself: refuse the uses
+        that would silently get no gradient."""
+        for name in self.names:
+            q = self.p(name)
+            if not q.requires_grad:
+                raise NotImplementedError(
+                    f"{name}: requires_grad=False on a single parameter is not served by the fused backward "
+                    "(it writes every gradient); freeze by leaving the parameter out of the optimizer")
+            if getattr(q, "_backward_hooks", None) or getattr(q, "_post_accumulate_grad_hooks", None):
+                raise NotImplementedError(
+                    f"{name} carries autograd hooks (DistributedDataParallel?): the fused backward writes p.grad as a "
+                    "side effect and hooks would never fire - all-reduce TrainableEncoder.flat_grad instead")
 
     def _off(self, layer: int, suffix: str) -> int:
         return layer * self._layer_stride + self._field_off[suffix]
@@ -275,3 +304,47 @@ class TrainableEncoder(nn.Module):
 def kd_step_scores(query_emb: torch.Tensor, doc_embs: torch.Tensor) -> torch.Tensor:
     """``torch.matmul(query_emb, doc_embs.T)[0]`` of the reference step (src/kd/train.py:189)."""
     return torch.matmul(query_emb, doc_embs.T)[0]
+
+
+class GraphedStep:
+    """ONE training step - every encoder forward, the loss, the backward pass and the optimizer update - captured into
+    a HIP graph and replayed (reference step: src/kd/train.py:176-210).
+
+    The KD step is ~800 short launches per 30 ms: replayed as one graph it no longer depends on how fast the host can
+    issue them (round 3 measured 111-132 ms for the same 30 ms of kernels on a box whose host cores were busy).
+    Nothing in the C-ABI allocates or synchronises, so every launch of a step is capturable; torch's caching allocator
+    serves the step's temporaries from the graph's private pool.
+
+    ``step_fn()`` runs one whole step on the CURRENT stream and returns a tensor (the loss) or a tuple of tensors; it
+    must read its batch from tensors that keep their storage (``GraphedStep.copy_inputs`` / ``tensor.copy_``) and must
+    not synchronise (no ``.item()``, no host reads).  The optimizer must be created with ``capturable=True``.
+    ``opt.zero_grad(set_to_none=True)`` inside ``step_fn`` is fine: the gradient views are re-attached during capture
+    and the memset of the flat gradient buffer is part of the graph."""
+
+    def __init__(self, step_fn, warmup: int = 3) -> None:
+        _native.require_gpu()
+        self._fn = step_fn
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):          # warm-up off the default stream, as torch's capture rules ask
+            for _ in range(max(int(warmup), 1)):
+                step_fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = step_fn()
+        self.steps_replayed = 0
+
+    def __call__(self):
+        self.graph.replay()
+        self.steps_replayed += 1
+        return self.out
+
+    @staticmethod
+    def copy_inputs(static: Sequence[torch.Tensor], fresh: Sequence[torch.Tensor]) -> None:
+        """copy the next batch into the tensors the captured step reads (same shapes)"""
+        for dst, src in zip(static, fresh):
+            if dst.shape != src.shape:
+                raise ValueError(f"a captured step has fixed shapes: {tuple(dst.shape)} != {tuple(src.shape)}")
+            dst.copy_(src, non_blocking=True)

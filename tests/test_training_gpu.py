@@ -279,3 +279,89 @@ def test_kd_step_at_bench_depth_and_geometry_vs_oracle(gpu):
     out2["loss"].backward()
     for name in ("encoder.layer.11.output.dense.weight", "embeddings.word_embeddings.weight"):
         assert _cos(model.p(name).grad.cpu().numpy(), grads[name]) > 0.9999, name
+
+
+@pytest.mark.gpu
+def test_graphed_kd_step_replays_the_eager_step(gpu):
+    """training.GraphedStep: the whole KD step (two encodes, q . d, the fused loss, backward, AdamW) captured into ONE
+    HIP graph.  Replayed for a few steps on changing batches it follows the eager step (reference step:
+    src/kd/train.py:176-210): same losses to 1e-3 relative and parameters within the tolerance that the
+    fp32-atomic weight-gradient sums leave between two eager runs."""
+    from semantic_search_kd_amd import BertConfig, synthetic_state_dict
+    from semantic_search_kd_amd.bench_support import synthetic_ids
+    from semantic_search_kd_amd.losses import CombinedKDLoss
+    from semantic_search_kd_amd.training import GraphedStep, TrainableEncoder
+
+    cfg = BertConfig(num_hidden_layers=2)
+    dev = torch.device("cuda:0")
+    tuples, docs = 4, 8
+    batches = []
+    for s in range(4):
+        q_ids, q_mask = synthetic_ids(tuples, 32, cfg.vocab_size, dev, seed=10 + s)
+        d_ids, d_mask = synthetic_ids(tuples * docs, 64, cfg.vocab_size, dev, seed=20 + s)
+        teacher = torch.randn((tuples, docs), generator=torch.Generator(device=dev).manual_seed(30 + s), device=dev) * 3.0
+        batches.append((q_ids, q_mask, d_ids, d_mask, teacher))
+
+    def run(graphed: bool):
+        model = TrainableEncoder(cfg, synthetic_state_dict(cfg), dev)
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True)
+        loss_fn = CombinedKDLoss()
+        static = [t.clone() for t in batches[0]]
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            q = model(static[0], static[1])
+            d = model(static[2], static[3]).view(tuples, docs, -1)
+            out = loss_fn(torch.einsum("th,tdh->td", q, d), static[4])
+            out["loss"].backward()
+            opt.step()
+            return out["loss"].detach()
+
+        losses = []
+        if graphed:
+            # the capture's warm-up steps train on batch 0: give the eager arm the same three steps (see below)
+            runner = GraphedStep(step, warmup=2)          # 2 warm-up steps + 1 captured step, all on batch 0
+        else:
+            for _ in range(3):
+                step()
+            runner = step
+        for b in batches:
+            GraphedStep.copy_inputs(static, b)
+            losses.append(float(runner()))
+        torch.cuda.synchronize()
+        return losses, {n: model.p(n).detach().cpu().numpy().copy() for n in model.names}
+
+    eager_losses, eager_params = run(False)
+    graph_losses, graph_params = run(True)
+    assert np.allclose(eager_losses, graph_losses, rtol=1e-3, atol=1e-4), (eager_losses, graph_losses)
+    assert eager_losses[-1] != eager_losses[0]
+    worst = max(float(np.abs(eager_params[n] - graph_params[n]).max()) for n in eager_params)
+    assert worst < 5e-4, worst                      # 7 AdamW steps at lr 1e-3 move a weight by up to 7e-3
+    moved = max(float(np.abs(eager_params[n] - synthetic_state_dict(cfg)[n]).max()) for n in eager_params)
+    assert moved > 2e-3, moved
+
+
+@pytest.mark.gpu
+def test_fused_backward_refuses_hooks_and_frozen_parameters(gpu):
+    """The HIP backward writes p.grad as a side effect (training._EncoderFunction.backward): uses that would silently
+    get no gradient fail loudly instead - a hook on a parameter (DDP's mechanism), a single frozen
+    parameter; the flat gradient buffer is what a data-parallel trainer reduces."""
+    from semantic_search_kd_amd.bench_support import synthetic_ids
+    from semantic_search_kd_amd.training import TrainableEncoder
+
+    cfg = BertConfig(num_hidden_layers=1)
+    dev = torch.device("cuda:0")
+    model = TrainableEncoder(cfg, synthetic_state_dict(cfg), dev)
+    ids, mask = synthetic_ids(2, 32, cfg.vocab_size, dev, seed=1)
+    model(ids, mask).sum().backward()
+    w = model.p("encoder.layer.0.output.dense.weight")
+    assert w.grad is not None and w.grad.untyped_storage().data_ptr() == model.flat_grad.untyped_storage().data_ptr()
+    assert float(model.flat_grad.abs().sum()) > 0
+    handle = w.register_hook(lambda g: g)
+    with pytest.raises(NotImplementedError, match="hooks"):
+        model(ids, mask)
+    handle.remove()
+    model(ids, mask)
+    w.requires_grad_(False)
+    with pytest.raises(NotImplementedError, match="requires_grad"):
+        model(ids, mask)

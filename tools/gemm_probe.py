@@ -57,4 +57,20 @@ for M, N, K, f32, acc, label in SHAPES:
             ref = a[rows].float() @ b.float().T
             err = ((c[rows].float() - ref).abs().max() / ref.abs().max()).item()
             line += f" err {err:.1e}" + ("" if err < 1.5e-2 else " MISMATCH")
+    # what the vendor library reaches on the same product (torch.nn.functional.linear -> hipBLASLt / rocBLAS): a yardstick, not
+    # a path of the product
+    if not f32:
+        import torch.nn.functional as F
+
+        bb = bias.to(torch.bfloat16)
+        for _ in range(3):
+            F.linear(a, b, bb)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            F.linear(a, b, bb)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        line += f" | torch linear: {ms * 1e3:8.1f} us {2.0 * M * N * K / ms / 1e9:7.1f} TF/s"
     print(line, flush=True)

@@ -1,11 +1,12 @@
-"""Turn the rocprofv3 passes of ``tools/prof_r03.sh search|big`` into ``profiles/r03/search_traffic.json`` and
+"""Turn the rocprofv3 passes of ``tools/prof_round.sh search|big`` into ``profiles/<round>/search_traffic.json`` and
 ``profiles/screen_traffic.json`` (what ``bench.py`` reads for ``roofline.traffic``):
-``python tools/make_search_traffic.py gpurun_out/r03_prof``.
+``python tools/make_search_traffic.py gpurun_out/<round>_prof``.
 
 Per search CALL: the screening step is ONE launch of ``screen_append_kernel`` (its bound-only sample phase runs inside
 it; builds that still launch a separate pre-pass - template argument ``true`` - are summed per call).
 FETCH_SIZE is doubled (gfx950 tallies 128-byte requests as 64 bytes), WRITE_SIZE is used as read; both are in KB."""
 import csv
+import os
 import re
 import hashlib
 import json
@@ -15,8 +16,9 @@ from collections import defaultdict
 from pathlib import Path
 
 REPO = Path(__file__).resolve().parent.parent
+ROUND = os.environ.get("ROUND", "r04")
 root = Path(sys.argv[1])
-NOTE = ("separate rocprofv3 passes (tools/prof_r03.sh): --kernel-trace --stats for durations, --pmc FETCH_SIZE and --pmc "
+NOTE = ("separate rocprofv3 passes (tools/prof_round.sh): --kernel-trace --stats for durations, --pmc FETCH_SIZE and --pmc "
         "WRITE_SIZE alone for traffic; FETCH_SIZE doubled per the gfx950 rule (128-B requests tallied as 64 B), WRITE_SIZE as "
         "read; HBM bytes = (2 FETCH + WRITE) x 1024 per search call (one launch of the screening kernel); program "
         "tools/ab_search.py (10 000 queries, k = 10, seeded unit rows)")
@@ -82,7 +84,7 @@ for tag, name, key, rows in (("shard", "screen_shard_1105228", "screen_append_ke
 if "exact_8841823" in out:   # B_q = 64 queries per pass at this shape
     passes = -(-10000 // 64)
     out["exact_8841823"]["algorithmic_hbm_bytes"] = passes * 8841823 * 1536
-dst = REPO / "profiles" / "r03" / "search_traffic.json"
+dst = REPO / "profiles" / ROUND / "search_traffic.json"
 dst.write_text(json.dumps(out, indent=1))
 print("wrote", dst)
 if "screen_1m" in out:
@@ -90,6 +92,6 @@ if "screen_1m" in out:
     (REPO / "profiles" / "screen_traffic.json").write_text(json.dumps({
         "kernel": "screen_append_kernel<10, 5, 12, 3, 2> (sample phase + slice phase in one launch)", "hbm_bytes_per_launch": e["hbm_bytes_per_launch"],
         "fetch_size_kb": e["fetch_size_kb"], "write_size_kb": e["write_size_kb"], "search_hip_sha": sha, "note": NOTE,
-        "from": f"profiles/r03/search_traffic.json@{head}"}, indent=1))
+        "from": f"profiles/{ROUND}/search_traffic.json@{head}"}, indent=1))
     print("wrote profiles/screen_traffic.json")
 print(json.dumps({k: {kk: v[kk] for kk in ("kernel_ms_avg", "hbm_counter_gbs", "tflops")} for k, v in out.items() if k != "meta"}, indent=1))

@@ -1,9 +1,10 @@
 #!/bin/bash
-# Round-3 profile passes (one gpurun call each part): kernel trace + stats, then separate --pmc passes.
-#   tools/prof_r03.sh search|big|encode|generic
+# Profile passes of a round (one gpurun call each part): kernel trace + stats, then separate --pmc passes.
+#   [ROUND=r04] tools/prof_round.sh search|big|encode|generic      (output: gpurun_out/${ROUND}_prof)
 set -e
+ROUND=${ROUND:-r04}
 LIB=$GRAFT_REPO_ROOT/semantic-search-kd_amd/libsskd_amd.so
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r03_prof; mkdir -p "$OUT"
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${ROUND}_prof; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 run() {  # run <tag> <rocprof args...> : the program is tools/ab_search.py on the in-tree library
   local tag=$1; shift
@@ -12,7 +13,7 @@ run() {  # run <tag> <rocprof args...> : the program is tools/ab_search.py on th
 }
 case "$1" in
 search)   # the bench shape: 10 000 queries x 1 M rows
-  bash $GRAFT_REPO_ROOT/tools/prof_search.sh "$LIB" r03_prof/screen_1m ;;
+  bash $GRAFT_REPO_ROOT/tools/prof_search.sh "$LIB" ${ROUND}_prof/screen_1m ;;
 big)      # BASELINE cfg 3: 8 841 823 rows whole (screened and exact) and the 1 105 228-row shard of one of 8 ranks
   export AB_NOCHECK=1 AB_ROUNDS=3
   AB_ROWS=1105228 run shard_trace --kernel-trace --stats
@@ -25,7 +26,7 @@ big)      # BASELINE cfg 3: 8 841 823 rows whole (screened and exact) and the 1 
   AB_ROWS=8841823 AB_EXACT=1 run whole_exact_fetch --pmc FETCH_SIZE
   AB_ROWS=8841823 AB_EXACT=1 run whole_exact_write --pmc WRITE_SIZE ;;
 encode)
-  bash $GRAFT_REPO_ROOT/tools/prof_encode.sh "$LIB" r03_prof/encode ;;
+  bash $GRAFT_REPO_ROOT/tools/prof_encode.sh "$LIB" ${ROUND}_prof/encode ;;
 generic)
-  bash $GRAFT_REPO_ROOT/tools/prof_generic.sh r03_prof/generic ;;
+  bash $GRAFT_REPO_ROOT/tools/prof_generic.sh ${ROUND}_prof/generic ;;
 esac
