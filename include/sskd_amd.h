@@ -418,6 +418,12 @@ int sskd_teacher_score(const sskd_generic_config* cfg, const sskd_generic_weight
  * product of the generic path goes through (test hook; K % 32 == 0). */
 int sskd_gemm_nt_bf16(const void* d_a, const void* d_b, void* d_c, const float* d_bias, int M, int N, int K,
                       int c_is_f32, int accumulate, void* stream);
+/* Which kernels serve the PLAIN large products of the generic path (C = A . W^T + bias, bf16 out, K and N >= 1024: the
+ * teacher's QKV, attention-output and FFN2 products): 0 = automatic - hipBLASLt, whose tuned kernels are 15-25 % faster
+ * there than this library's 256 x 256 MFMA kernel; 1 = this library's kernels only (tests, A/B probes).  Any other value
+ * only queries.  Process-wide; returns the mode in force.  Products with a fused epilogue, K = 384 (student) products,
+ * batched / fp32 / accumulating products always run on the hand-written kernels. */
+int sskd_gemm_backend(int mode);
 /* C[M, N] (fp32) += A[T, M]^T . B[T, N]: the weight-gradient product of the training step with the token
  * dimension as the row of both bf16 operands (test hook; M % 384 == 0, N % 128 == 0, T % 64 == 0, else
  * SSKD_ERR_UNSUPPORTED: the step then transposes and uses the NT kernel). */

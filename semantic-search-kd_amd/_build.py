@@ -18,7 +18,7 @@ INCLUDE = REPO_ROOT / "include"
 OBJ_DIR = PKG_DIR / "build"
 LIB_PATH = PKG_DIR / "libsskd_amd.so"
 
-SOURCES = ["capi_common.hip", "search.hip", "pool.hip", "encoder.hip", "kd_loss.hip", "tokenizer.hip", "generic.hip", "train.hip"]
+SOURCES = ["capi_common.hip", "search.hip", "pool.hip", "encoder.hip", "kd_loss.hip", "tokenizer.hip", "generic.hip", "train.hip", "blaslt.hip"]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",
     "-O3",
@@ -65,7 +65,8 @@ def build_native(force: bool = False, verbose: bool = False) -> Path:
             rebuilt = True
         objs.append(obj)
     if rebuilt or force or not _newer(LIB_PATH, objs):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", str(LIB_PATH), *map(str, objs)]
+        # hipBLASLt: plain large-K library GEMMs of the teacher (csrc/blaslt.hip); everything else is this repo's kernels
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", str(LIB_PATH), *map(str, objs), "-lhipblaslt"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -157,6 +157,7 @@ SIGNATURES = {
         _i, [C.POINTER(GenericConfig), C.POINTER(GenericWeights), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]
     ),
     "sskd_gemm_nt_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sskd_gemm_backend": (_i, [_i]),
     "sskd_gemm_tn_bf16": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
     "sskd_tokenizer_create": (_i, [C.c_char_p, _i64, C.POINTER(C.c_void_p)]),
     "sskd_tokenizer_destroy": (None, [_vp]),

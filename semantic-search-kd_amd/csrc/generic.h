@@ -29,6 +29,12 @@ struct GemmArgs {
 };
 
 int launch_gemm_nt(const GemmArgs& a, hipStream_t st);
+// blaslt.hip: plain large-K products (K, N >= 1024, bf16 out, bias only) go through hipBLASLt; returns false when the
+// product is not one of those (the caller launches the hand-written kernel).  set_gemm_backend(1) keeps everything on
+// the hand-written kernels (tests, A/B probes); 0 = automatic.
+bool blaslt_gemm_nt(const GemmArgs& a, hipStream_t st, int* rc);
+void set_gemm_backend(int mode);
+int gemm_backend();
 
 // Weight-gradient product with NO operand transposes: C[M, N] (fp32) += A[T, M]^T B[T, N], the reduction (token)
 // dimension being the ROW of both row-major operands.  T is cut over workgroups, partial tiles meet through fp32

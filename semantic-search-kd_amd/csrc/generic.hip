@@ -1514,6 +1514,10 @@ int launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
   SSKD_REQUIRE(!a.accumulate || a.c_is_f32, "gemm_nt: accumulate needs an fp32 output");
   SSKD_REQUIRE(a.split_k <= 1 || (a.accumulate && a.c_is_f32 && a.batch1 * a.batch2 == 1 && !a.bias),
                "gemm_nt: split-K needs an unbatched fp32 accumulating output without bias");
+  {
+    int rc = SSKD_OK;
+    if (blaslt_gemm_nt(a, st, &rc)) return rc;   // plain large-K product: the vendor library's kernel (blaslt.hip)
+  }
   const dim3 grid((unsigned)sskd::ceil_div(a.N, 128), (unsigned)sskd::ceil_div(a.M, 128),
                   (unsigned)(a.split_k > 1 ? a.split_k : a.batch1 * a.batch2));
   const bool big = a.batch1 * a.batch2 == 1 && a.split_k <= 1 && !a.c_is_f32 && a.M % 256 == 0 && a.N % 128 == 0 &&

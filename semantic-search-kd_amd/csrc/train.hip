@@ -641,6 +641,11 @@ int sskd_teacher_score(const sskd_generic_config* cfg, const sskd_generic_weight
 }
 
 // test hook: the NT GEMM by itself
+int sskd_gemm_backend(int mode) {
+  if (mode == 0 || mode == 1) sskd_generic::set_gemm_backend(mode);
+  return sskd_generic::gemm_backend();
+}
+
 int sskd_gemm_nt_bf16(const void* d_a, const void* d_b, void* d_c, const float* d_bias, int M, int N, int K, int c_is_f32,
                       int accumulate, void* stream) {
   return gemm(static_cast<const bf16_t*>(d_a), K, static_cast<const bf16_t*>(d_b), K, d_c, N, M, N, K, d_bias,

@@ -74,6 +74,42 @@ def test_nt_gemm_matches_torch(gpu, native_lib):
 
 
 @pytest.mark.gpu
+def test_plain_large_k_products_library_route_matches_own_kernel(gpu, native_lib):
+    """csrc/blaslt.hip: the teacher's plain products (K, N >= 1024, bias only, bf16 out) go through hipBLASLt in
+    automatic mode and through the 256 x 256 MFMA kernel with sskd_gemm_backend(1); both against torch in fp32, with
+    and without a bias, with a leading dimension larger than the row (the QKV output is consumed as three column
+    blocks), and the switch itself (query, set, restore)."""
+    from semantic_search_kd_amd import _native
+
+    lib = native_lib
+    assert lib.sskd_gemm_backend(-1) == 0           # default: automatic
+    g = torch.Generator(device="cuda").manual_seed(1)
+    st = int(torch.cuda.current_stream().cuda_stream)
+    try:
+        for M, N, K, use_bias in ((2048, 3072, 1024, True), (1024, 1024, 1024, True), (2048, 1024, 4096, True),
+                                  (4096, 1024, 1024, False), (1024, 2048, 2048, True)):
+            a = torch.randn((M, K), generator=g, device="cuda").to(torch.bfloat16)
+            b = (torch.randn((N, K), generator=g, device="cuda") / K ** 0.5).to(torch.bfloat16)
+            bias = torch.randn(N, generator=g, device="cuda")
+            want = a.float() @ b.float().T + (bias if use_bias else 0)
+            got = {}
+            for mode in (1, 0):
+                assert lib.sskd_gemm_backend(mode) == mode
+                c = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+                _native.check(lib.sskd_gemm_nt_bf16(a.data_ptr(), b.data_ptr(), c.data_ptr(), bias.data_ptr() if use_bias else None,
+                                                    M, N, K, 0, 0, st))
+                torch.cuda.synchronize()
+                err = (c.float() - want).abs().max().item()
+                assert err <= 2e-2 * want.abs().max().item(), (mode, M, N, K, err)
+                got[mode] = c
+            # two correct bf16 roundings of the same product: equal almost everywhere, never more than an ulp or two apart
+            d = (got[0].float() - got[1].float()).abs()
+            assert d.max().item() <= 4e-2 * want.abs().max().item() and (d > 0).float().mean().item() < 0.2
+    finally:
+        lib.sskd_gemm_backend(0)
+
+
+@pytest.mark.gpu
 def test_tn_gemm_matches_torch(gpu, native_lib):
     """C += A^T B with the token dimension as the row of both operands (transposing LDS reads, split over K)."""
     from semantic_search_kd_amd import _native
@@ -319,10 +355,11 @@ def test_graphed_kd_step_replays_the_eager_step(gpu):
 
         losses = []
         if graphed:
-            # the capture's warm-up steps train on batch 0: give the eager arm the same three steps (see below)
-            runner = GraphedStep(step, warmup=2)          # 2 warm-up steps + 1 captured step, all on batch 0
+            # the capture's two warm-up steps train on batch 0 (the captured step itself is only recorded, not run):
+            # the eager arm takes the same two steps
+            runner = GraphedStep(step, warmup=2)
         else:
-            for _ in range(3):
+            for _ in range(2):
                 step()
             runner = step
         for b in batches:
@@ -336,7 +373,7 @@ def test_graphed_kd_step_replays_the_eager_step(gpu):
     assert np.allclose(eager_losses, graph_losses, rtol=1e-3, atol=1e-4), (eager_losses, graph_losses)
     assert eager_losses[-1] != eager_losses[0]
     worst = max(float(np.abs(eager_params[n] - graph_params[n]).max()) for n in eager_params)
-    assert worst < 5e-4, worst                      # 7 AdamW steps at lr 1e-3 move a weight by up to 7e-3
+    assert worst < 5e-4, worst                      # 6 AdamW steps at lr 1e-3 move a weight by up to 6e-3
     moved = max(float(np.abs(eager_params[n] - synthetic_state_dict(cfg)[n]).max()) for n in eager_params)
     assert moved > 2e-3, moved
 

@@ -24,5 +24,5 @@ for spec_ in sys.argv[1:]:
     subprocess.run([b._hipcc(), *b.HIPCC_FLAGS, *extra, f"-I{b.INCLUDE}", f"-I{b.CSRC}", "-c", str(b.CSRC / source), "-o", str(obj)], check=True)
     others = [b.OBJ_DIR / (Path(s).stem + ".o") for s in b.SOURCES if s != source]
     lib = out_dir / f"lib_{name}.so"
-    subprocess.run([b._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib), str(obj), *map(str, others)], check=True)
+    subprocess.run([b._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib), str(obj), *map(str, others), "-lhipblaslt"], check=True)
     print("built", lib)

@@ -32,7 +32,13 @@ for pth in paths:
     lib = C.CDLL(str(Path(pth).resolve()))
     fn = lib.sskd_gemm_nt_bf16
     fn.restype, fn.argtypes = _native.SIGNATURES["sskd_gemm_nt_bf16"]
-    libs.append((Path(pth).stem, fn))
+    if hasattr(lib, "sskd_gemm_backend"):   # both routes of one library: its own kernels only, then automatic (hipBLASLt
+        be = lib.sskd_gemm_backend          # for the plain large-K products)
+        be.restype, be.argtypes = _native.SIGNATURES["sskd_gemm_backend"]
+        libs.append((Path(pth).stem + "[own]", lambda *a, fn=fn, be=be: (be(1), fn(*a))[1]))
+        libs.append((Path(pth).stem + "[auto]", lambda *a, fn=fn, be=be: (be(0), fn(*a))[1]))
+    else:
+        libs.append((Path(pth).stem, fn))
 st = int(torch.cuda.current_stream(dev).cuda_stream)
 for M, N, K, f32, acc, label in SHAPES:
     a = (torch.rand((M, K), device=dev) - 0.5).to(torch.bfloat16)
@@ -73,4 +79,17 @@ for M, N, K, f32, acc, label in SHAPES:
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 10
         line += f" | torch linear: {ms * 1e3:8.1f} us {2.0 * M * N * K / ms / 1e9:7.1f} TF/s"
+    if f32 and acc:   # weight-gradient shape: the vendor library on C[M, N] = A[K, M]^T B[K, N] (token-major operands, as dW has them)
+        at = (torch.rand((K, M), device=dev) - 0.5).to(torch.bfloat16)
+        bt = (torch.rand((K, N), device=dev) - 0.5).to(torch.bfloat16)
+        for _ in range(3):
+            torch.mm(at.t(), bt)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            torch.mm(at.t(), bt)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        line += f" | torch mm(A^T, B) bf16 out: {ms * 1e3:8.1f} us {2.0 * M * N * K / ms / 1e9:7.1f} TF/s"
     print(line, flush=True)
