@@ -306,6 +306,20 @@ class Mi355xSentenceEncoder:
         self._forward_rows(lib, ids, mask, normalize, out, torch.cuda.current_stream(self.device), "_workspace")
         return out
 
+    def capture_forward(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                        normalize: bool = True, out: Optional[torch.Tensor] = None) -> "GraphedForward":
+        """The forward over a FIXED ``[B, S]`` shape captured into one HIP graph (26 launches at 12 layers): the caller
+        keeps refilling ``input_ids`` / ``attention_mask`` (device int32 tensors, same storage) and calls ``replay()``;
+        the embeddings land in ``.out``.  For loops that encode many equally shaped batches (index builds at a fixed
+        token budget, the bench): the launches no longer depend on the host's pace."""
+        ids = _as_device_i32(input_ids, self.device)
+        mask = torch.ones_like(ids) if attention_mask is None else _as_device_i32(attention_mask, self.device)
+        if ids.data_ptr() != (input_ids.data_ptr() if isinstance(input_ids, torch.Tensor) else 0):
+            raise ValueError("capture_forward needs device int32 tensors (the graph reads THEIR storage at every replay)")
+        if out is None:
+            out = torch.empty((ids.shape[0], self.config.hidden_size), dtype=torch.float32, device=self.device)
+        return GraphedForward(self, ids, mask, bool(normalize), out)
+
     def _forward_rows(self, lib, ids, mask, normalize, out, stream, ws_name: str) -> None:
         B, S = ids.shape
         need = int(lib.sskd_encoder_workspace_bytes(self.weights.cstruct_cfg, B, S))
@@ -651,3 +665,27 @@ def _read_st_max_len(model_dir: Optional[Path]) -> Optional[int]:
         except Exception:
             return None
     return None
+
+
+class GraphedForward:
+    """``Mi355xSentenceEncoder.capture_forward``: one captured forward over fixed-shape inputs."""
+
+    def __init__(self, enc: "Mi355xSentenceEncoder", ids: torch.Tensor, mask: torch.Tensor, normalize: bool, out: torch.Tensor) -> None:
+        self.enc, self.ids, self.mask, self.normalize, self.out = enc, ids, mask, normalize, out
+        enc.sync_inference_weights()
+        self._weights = enc.weights
+        side = torch.cuda.Stream(enc.device)
+        side.wait_stream(torch.cuda.current_stream(enc.device))
+        with torch.cuda.stream(side):          # warm-up off the capture stream: workspace allocation, code load
+            enc.encode_token_ids(ids, mask, normalize=normalize, out=out)
+        torch.cuda.current_stream(enc.device).wait_stream(side)
+        torch.cuda.synchronize(enc.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            enc.encode_token_ids(ids, mask, normalize=normalize, out=out)
+
+    def replay(self) -> torch.Tensor:
+        if self.enc.weights is not self._weights or self.enc.sync_inference_weights():
+            raise RuntimeError("the encoder's weights changed since this forward was captured: capture it again")
+        self.graph.replay()
+        return self.out

@@ -279,3 +279,28 @@ def test_model_name_is_never_fetched(gpu):
         StudentModel("intfloat/e5-small-v2", device="cuda:0")
     with pytest.raises(RuntimeError, match="MI355X only"):
         StudentModel("whatever", device="cpu")
+
+
+@pytest.mark.gpu
+def test_captured_forward_replays_the_eager_forward(gpu):
+    """Mi355xSentenceEncoder.capture_forward: the fixed-shape forward as one HIP graph - same bits as the eager
+    launches, follows refilled inputs, refuses to run on weights that changed after the capture."""
+    from semantic_search_kd_amd import BertConfig, Mi355xSentenceEncoder
+    from semantic_search_kd_amd.bench_support import synthetic_ids
+
+    cfg = BertConfig(num_hidden_layers=2)
+    enc = Mi355xSentenceEncoder.from_synthetic(cfg, device="cuda:0")
+    ids, mask = synthetic_ids(64, 96, cfg.vocab_size, torch.device("cuda:0"), seed=3)
+    want = enc.encode_token_ids(ids, mask).clone()
+    fwd = enc.capture_forward(ids, mask)
+    assert torch.equal(fwd.replay(), want)
+    ids2, mask2 = synthetic_ids(64, 96, cfg.vocab_size, torch.device("cuda:0"), seed=4)
+    want2 = enc.encode_token_ids(ids2, mask2).clone()
+    ids.copy_(ids2)
+    mask.copy_(mask2)
+    assert torch.equal(fwd.replay(), want2) and not torch.equal(want, want2)
+    from semantic_search_kd_amd.weights import DeviceWeights
+
+    enc.weights = DeviceWeights(cfg, enc._host_state, enc.device)      # e.g. after a training step re-tiled them
+    with pytest.raises(RuntimeError, match="weights changed"):
+        fwd.replay()
