@@ -152,6 +152,12 @@ int sskd_index_search_profiled(const float* d_tiled, int64_t n_rows,
  * fp32 rows row-major (1536 B per row: the re-scoring gathers read whole cache lines from it). */
 size_t sskd_index_bf16_bytes(int64_t n_rows);
 int sskd_index_make_bf16(const float* d_tiled, int64_t n_rows, void* d_bf16, void* stream);
+/* COMPACT sidecar: the bf16 tiles and the norm block only (768 B per row: the index then costs 1.5x the corpus instead of
+ * 2.5x).  sskd_index_search_screened reads which form it was given from the sidecar itself and re-scores the candidates
+ * from the fp32 TILES instead of the row-major copy: same output bits, the re-scoring gathers touch 96 cache lines per
+ * row instead of 12 (measured cost in DESIGN.md section 2). */
+size_t sskd_index_bf16_bytes_compact(int64_t n_rows);
+int sskd_index_make_bf16_compact(const float* d_tiled, int64_t n_rows, void* d_bf16, void* stream);
 size_t sskd_index_search_screened_workspace_bytes(int64_t n_rows, int nq, int k);
 /* launch geometry of the screening pass (roofline accounting): queries per workgroup, corpus passes, slices */
 int sskd_index_search_screened_plan(int64_t n_rows, int nq, int k, int* queries_per_block, int* corpus_passes,

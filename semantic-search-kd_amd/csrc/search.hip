@@ -840,6 +840,7 @@ __global__ __launch_bounds__(256) void tile_colsum_kernel(const float4* __restri
 // non-negative floats), floats [64 .. 64 + 384) = column sums, then the mean row
 constexpr int SIDECAR_NORM_BYTES = 4096;
 constexpr int SIDECAR_COLSUM_OFF = 64;   // in floats
+constexpr int SIDECAR_HAS_ROWS_WORD = 8; // int [8]: 1 = the row-major fp32 rows follow the norm block, 0 = compact sidecar
 
 __global__ __launch_bounds__(256) void make_bf16_tiles_kernel(const float4* __restrict__ tiled, int64_t n_tiles, int64_t n_rows,
                                                               sbf16x8* __restrict__ out, int* __restrict__ norm_block,
@@ -871,9 +872,11 @@ __global__ __launch_bounds__(256) void make_bf16_tiles_kernel(const float4* __re
       dd = fmaf(d, d, dd);
     }
     out[t * BTILE_VEC + v] = o;
-    float4* const dst = rows_rm + (t * TILE_ROWS + r) * (int64_t)(DIM / 4) + 2 * u;  // columns 8u .. 8u + 7
-    dst[0] = a;
-    dst[1] = b;
+    if (rows_rm) {   // (absent in a COMPACT sidecar: the finalize kernel then gathers from the fp32 tiles)
+      float4* const dst = rows_rm + (t * TILE_ROWS + r) * (int64_t)(DIM / 4) + 2 * u;  // columns 8u .. 8u + 7
+      dst[0] = a;
+      dst[1] = b;
+    }
     atomicAdd(&rowss[0][r], nn);
     atomicAdd(&rowss[1][r], bb);
     atomicAdd(&rowss[2][r], dd);
@@ -1282,6 +1285,8 @@ struct ScreenFinalAppendParams {
   const int* cand_cnt;        // [nq][lists]
   const float* eps2;
   const float* rows;          // fp32 rows, row-major (the sidecar's copy): exact re-scoring
+  const float4* tiled;        // the fp32 index tiles: what a COMPACT sidecar (no row-major copy) re-scores from
+  const int* norm_block;      // the sidecar's norm block: word SIDECAR_HAS_ROWS_WORD says which of the two to read
   const float* queries;
   int lists, k, nq;
   int64_t id_offset;
@@ -1457,6 +1462,10 @@ __global__ __launch_bounds__(64) void screen_finalize_append_kernel(ScreenFinalA
   __builtin_amdgcn_s_waitcnt(0xC07F);
 
   // exact scores, 64 candidates per round: the fma order of the 32x32x2 f32 MFMA chain (section 3.1).
+  // Rows come from the sidecar's row-major copy (a row = 12 whole cache lines) or, with a COMPACT sidecar, from the fp32
+  // tiles themselves: element (row, step u, half hb) is float4 (tile 48 + u) 64 + (row & 31) + 32 hb - 96 lines of
+  // which 16 bytes each are used, the price of keeping one fp32 copy instead of two.
+  const bool rows_rm = __builtin_amdgcn_readfirstlane(p.norm_block[SIDECAR_HAS_ROWS_WORD]) != 0;
   float cs[SCREEN_MAX_CAND / 64];
   int cid[SCREEN_MAX_CAND / 64];
 #pragma unroll
@@ -1466,11 +1475,13 @@ __global__ __launch_bounds__(64) void screen_finalize_append_kernel(ScreenFinalA
     const int idx = c * 64 + lane;
     if (idx < M) {
       const int row = ci[idx];
-      const float4* src = reinterpret_cast<const float4*>(p.rows) + (int64_t)row * (DIM / 4);
+      const float4* src = rows_rm ? reinterpret_cast<const float4*>(p.rows) + (int64_t)row * (DIM / 4)
+                                  : p.tiled + (int64_t)(row >> 5) * (TILE_ROWS * CHUNKS) + (row & 31);
+      const int su = rows_rm ? 2 : 64, sh = rows_rm ? 1 : 32;   // float4 strides of a step / of its second half
       float acc = 0.f;
 #pragma unroll 16
       for (int u = 0; u < STEPS; ++u) {  // 16 steps = four whole 128-byte lines of the row in flight
-        const float4 a = src[2 * u], b = src[2 * u + 1];
+        const float4 a = src[su * u], b = src[su * u + sh];
         const float4 qa = *reinterpret_cast<const float4*>(&qv[8 * u]), qb = *reinterpret_cast<const float4*>(&qv[8 * u + 4]);
         acc = fmaf(a.x, qa.x, acc); acc = fmaf(b.x, qb.x, acc);
         acc = fmaf(a.y, qa.y, acc); acc = fmaf(b.y, qb.y, acc);
@@ -2195,15 +2206,32 @@ size_t sskd_index_bf16_bytes(int64_t n_rows) {
   return sidecar_rows_offset(n_rows) + (size_t)sskd_index_padded_rows(n_rows) * DIM * sizeof(float);
 }
 
+size_t sskd_index_bf16_bytes_compact(int64_t n_rows) {
+  if (n_rows <= 0) return 0;
+  return sidecar_rows_offset(n_rows);
+}
+
+static int make_bf16_impl(const float* d_tiled, int64_t n_rows, void* d_bf16, void* stream, bool with_rows);
+
 int sskd_index_make_bf16(const float* d_tiled, int64_t n_rows, void* d_bf16, void* stream) {
+  return make_bf16_impl(d_tiled, n_rows, d_bf16, stream, true);
+}
+
+int sskd_index_make_bf16_compact(const float* d_tiled, int64_t n_rows, void* d_bf16, void* stream) {
+  return make_bf16_impl(d_tiled, n_rows, d_bf16, stream, false);
+}
+
+static int make_bf16_impl(const float* d_tiled, int64_t n_rows, void* d_bf16, void* stream, bool with_rows) {
   SSKD_REQUIRE(n_rows >= 0, "index_make_bf16: n_rows < 0");
   if (n_rows == 0) return SSKD_OK;
   SSKD_REQUIRE(d_tiled && d_bf16, "index_make_bf16: null pointer");
   hipStream_t st = sskd::as_stream(stream);
   const int64_t tiles = sskd::ceil_div(n_rows, TILE_ROWS);
   int* max_norm2 = reinterpret_cast<int*>(static_cast<char*>(d_bf16) + sidecar_norm_offset(n_rows));
-  float4* rows_rm = reinterpret_cast<float4*>(static_cast<char*>(d_bf16) + sidecar_rows_offset(n_rows));
+  float4* rows_rm = with_rows ? reinterpret_cast<float4*>(static_cast<char*>(d_bf16) + sidecar_rows_offset(n_rows)) : nullptr;
   if (hipMemsetAsync(max_norm2, 0, SIDECAR_NORM_BYTES, st) != hipSuccess) return sskd::fail(SSKD_ERR_HIP, "index_make_bf16: memset failed");
+  if (with_rows && hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(max_norm2 + SIDECAR_HAS_ROWS_WORD), 1, 1, st) != hipSuccess)
+    return sskd::fail(SSKD_ERR_HIP, "index_make_bf16: memset failed");
   hipLaunchKernelGGL(tile_colsum_kernel, dim3((unsigned)(tiles < 1024 ? tiles : 1024)), dim3(256), 0, st,
                      reinterpret_cast<const float4*>(d_tiled), tiles, reinterpret_cast<float*>(max_norm2) + SIDECAR_COLSUM_OFF);
   int rc = sskd::check_launch("tile_colsum_kernel");
@@ -2299,7 +2327,9 @@ int sskd_index_search_screened(const float* d_tiled, const void* d_bf16, int64_t
   fp.cand = sp.cand;
   fp.cand_cnt = w.cand_cnt;
   fp.eps2 = w.eps2;
-  fp.rows = reinterpret_cast<const float*>(static_cast<const char*>(d_bf16) + sidecar_rows_offset(n_rows));
+  fp.rows = reinterpret_cast<const float*>(static_cast<const char*>(d_bf16) + sidecar_rows_offset(n_rows));   // (only read when the sidecar has them)
+  fp.tiled = reinterpret_cast<const float4*>(d_tiled);
+  fp.norm_block = max_norm2;
   fp.queries = d_queries;
   fp.lists = pl.lists_per_query;
   fp.k = k;
