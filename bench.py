@@ -688,8 +688,8 @@ def main() -> None:
             "search_path": "bf16-screened + exact fp32 re-scoring (bit-identical to the exact scan)" if use_screen
             else "exact fp32 scan",
             "exact_fallback_queries": int(status[1].item()) if use_screen else 0,
-            # HBM held by this rank's shard: the fp32 tiles (the index proper), the screening sidecar (bf16 tiles +
-            # norms) and the per-call workspace of the timed path
+            # HBM held by this rank's shard: the fp32 index (one row-major copy: scan, re-scoring, save), the screening
+            # sidecar (bf16 tiles + norms) and the per-call workspace of the timed path
             "index_bytes": int(lib.sskd_index_tiled_bytes(n_local)),
             "sidecar_bytes": int(lib.sskd_index_bf16_bytes(n_local)) if use_screen else 0,
             "workspace_bytes": int(ws_bytes),
@@ -721,21 +721,6 @@ def main() -> None:
             "hbm_peak_gbs": HBM_PEAK_GBS,
         })
 
-    # ---- the same step with the COMPACT sidecar (no second fp32 copy of the rows: index = 1.5x the corpus) ----------
-    if rank == 0 and world == 1 and use_screen:
-        index.compact_sidecar = True
-        index._bf16_rows = -1
-        c_ms, c_kms, c_st, c_s, c_i = _time_search(index, queries, K, 5, ev, lib, n_local, lo, True)
-        line["search_compact_sidecar"] = {
-            "value": round(nq / c_ms * 1e3, 1), "unit": "queries/s", "ms_per_step": round(c_ms, 4),
-            "sidecar_bytes": int(lib.sskd_index_bf16_bytes_compact(n_local)),
-            "index_plus_sidecar_over_corpus": round((int(lib.sskd_index_tiled_bytes(n_local)) + int(lib.sskd_index_bf16_bytes_compact(n_local)))
-                                                    / (n_local * DIM * 4.0), 3),
-            "equals_default_sidecar_all_rows": bool(torch.equal(c_i, res[1]) and torch.equal(c_s, res[0])),
-            "note": "candidates re-scored from the fp32 tiles (96 cache lines per row) instead of the sidecar's row-major copy (12)",
-        }
-        index.compact_sidecar = False
-        index._bf16_rows = -1
     # ---- hostile-data leg and the cfg-3 sizes (rank 0, N = 1) -----------------------------------------------------
     if rank == 0 and world == 1 and not args.no_hostile and n >= 100_000:
         line["search_anisotropic"] = bench_search_anisotropic(pkg, lib, dev, n, nq, ev)

@@ -57,15 +57,16 @@ int sskd_device_count(void);
  *   reference: scripts/build_faiss_index.py:55-62 (build_from_parquet),
  *              tests/conftest.py:184-185 (IndexFlatIP(384); index.add(x)),
  *              configs/index.yaml:30 (normalize: true)
- * The index lives in HBM as 32-row tiles laid out in MFMA-fragment order:
- *   tile t, step u (0..47), lane l (0..63) holds row 32t + (l & 31),
- *   columns 8u + 4(l >> 5) + {0,1,2,3}   -> 16 B per lane, 1 KiB per step,
- *   48 KiB per tile; rows past n_rows in the last tile are zero.
+ * The index lives in HBM as the plain ROW-MAJOR fp32 matrix (1 536 B per row), zero-padded to a multiple of 32
+ * rows ("tile" = 32 consecutive rows: lane l of a scanning wave owns row 32t + (l & 31) and the column half
+ * 4 (l >> 5) of every 8-column k-step).  The `d_tiled` / `tiled` names of this API date from rounds 1-3, when the
+ * tiles were stored in MFMA-fragment order and the screening sidecar carried a second, row-major fp32 copy; callers
+ * treat the buffer as opaque (sskd_index_tiled_bytes, sskd_index_add_rows, sskd_index_get_rows).
  * ------------------------------------------------------------------------- */
 int64_t sskd_index_padded_rows(int64_t n_rows);
 size_t sskd_index_tiled_bytes(int64_t n_rows);
 
-/* Copy `n_rows` row-major fp32 rows into the tiled index starting at index row
+/* Copy `n_rows` row-major fp32 rows into the index starting at index row
  * `dst_row0` (must be a multiple of 32), optionally L2-normalising each row
  * (x / ||x||_2, rows of zero norm left untouched: faiss.normalize_L2).
  * The last partial tile written is zero-padded. */
@@ -147,17 +148,12 @@ int sskd_index_search_profiled(const float* d_tiled, int64_t n_rows,
  * stability), [1] = the number of queries that took the exact fallback (a cost diagnostic).  ev_scan_begin /
  * ev_scan_end bracket the screening launch (a bound-only sample phase over the shard's first rows, then the slices).  d_bf16: the screening sidecar,
  * sskd_index_bf16_bytes(n_rows) bytes filled by sskd_index_make_bf16 from the CURRENT tiled index
- * (re-make it after sskd_index_add_rows): the bf16 tiles of the centred rows (768 B per row), a 4-KiB
- * block with max |row|^2, max |row~|^2, max |row~ - (row - mean)|^2 and the column sums, and the ORIGINAL
- * fp32 rows row-major (1536 B per row: the re-scoring gathers read whole cache lines from it). */
+ * (re-make it after sskd_index_add_rows): the bf16 tiles of the centred rows (768 B per row) and a 4-KiB
+ * block with max |row|^2, max |row~|^2, max |row~ - (row - mean)|^2 and the column sums.  Exact re-scoring
+ * reads the fp32 index itself (row-major since round 4: index + sidecar = 1.5x the corpus; rounds 2-3 kept a
+ * second fp32 copy in the sidecar, 2.5x). */
 size_t sskd_index_bf16_bytes(int64_t n_rows);
 int sskd_index_make_bf16(const float* d_tiled, int64_t n_rows, void* d_bf16, void* stream);
-/* COMPACT sidecar: the bf16 tiles and the norm block only (768 B per row: the index then costs 1.5x the corpus instead of
- * 2.5x).  sskd_index_search_screened reads which form it was given from the sidecar itself and re-scores the candidates
- * from the fp32 TILES instead of the row-major copy: same output bits, the re-scoring gathers touch 96 cache lines per
- * row instead of 12 (measured cost in DESIGN.md section 2). */
-size_t sskd_index_bf16_bytes_compact(int64_t n_rows);
-int sskd_index_make_bf16_compact(const float* d_tiled, int64_t n_rows, void* d_bf16, void* stream);
 size_t sskd_index_search_screened_workspace_bytes(int64_t n_rows, int nq, int k);
 /* launch geometry of the screening pass (roofline accounting): queries per workgroup, corpus passes, slices */
 int sskd_index_search_screened_plan(int64_t n_rows, int nq, int k, int* queries_per_block, int* corpus_passes,

@@ -123,9 +123,7 @@ SIGNATURES = {
     "sskd_topk_record_bytes": (_sz, [_i, _i]),
     "sskd_topk_merge_packed": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "sskd_index_bf16_bytes": (_sz, [_i64]),
-    "sskd_index_bf16_bytes_compact": (_sz, [_i64]),
     "sskd_index_make_bf16": (_i, [_vp, _i64, _vp, _vp]),
-    "sskd_index_make_bf16_compact": (_i, [_vp, _i64, _vp, _vp]),
     "sskd_index_search_screened_workspace_bytes": (_sz, [_i64, _i, _i]),
     "sskd_index_search_screened_plan": (_i, [_i64, _i, _i, _ip, _ip, _ip]),
     "sskd_index_search_screened": (_i, [_vp, _vp, _i64, _vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),

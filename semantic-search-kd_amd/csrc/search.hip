@@ -1,14 +1,14 @@
-// Exact inner-product top-k over a tiled fp32 corpus in HBM (gfx950 / MI355X).
+// Exact inner-product top-k over an fp32 corpus in HBM (gfx950 / MI355X).
 //
 // Replaces faiss `index.add` / `index.search` behind the reference's
 // FAISSIndexBuilder (reference: src/serve/app.py:293-301,
 // scripts/build_faiss_index.py:49-62, tests/conftest.py:184-185) and the
 // exact-search idiom `np.argsort(scores)[::-1][:k]` (src/kd/eval.py:86).
 //
-// Data layout (see include/sskd_amd.h): 32-row tiles, each stored as 48 steps
-// of 1 KiB in exactly the order the 64 lanes of a wave consume them as the A
-// operand of v_mfma_f32_32x32x2_f32, so every wave-instruction of the scan is
-// one contiguous 1 KiB read.
+// Data layout (see include/sskd_amd.h): the index is the plain row-major fp32
+// matrix, zero-padded to a multiple of 32 rows; a "tile" is 32 consecutive rows
+// and lane l of a wave reads its A-operand k-steps straight from row
+// 32 t + (l & 31) (details and the round-4 measurement beside STEP_FLOATS below).
 //
 // Scan kernel: one workgroup = one block of 32*QB queries (held in LDS in
 // B-operand order) x one slice of corpus tiles.  Each wave streams its own
@@ -32,7 +32,17 @@ constexpr int CHUNKS = DIM / 4;               // 96 float4 chunks per row
 constexpr int TILE_FLOATS = TILE_ROWS * DIM;  // 12288 floats = 48 KiB
 constexpr int GROUP = 8;                      // k-steps per prefetch group
 constexpr int GROUPS = STEPS / GROUP;         // 6 (even: groups alternate A/B)
-constexpr int STEP_FLOATS = 64 * 4;           // one wave-instruction: 1 KiB
+// The index is a plain ROW-MAJOR fp32 matrix (1 536 B per row), padded with zero rows to a multiple of 32; a "tile" is 32
+// consecutive rows.  Lane l of a wave owns row 32 t + (l & 31) of its tile and the column half 4 (l >> 5): k-step u of the
+// A operand of v_mfma_f32_32x32x2_f32 is the 16 bytes at columns 8 u + 4 (l >> 5) of that row - a wave-instruction reads 32
+// row segments of 32 B, and four consecutive k-steps use every byte of the 128-byte lines they touch.  (Rounds 1-3 stored
+// the tiles in MFMA-fragment order - one contiguous KiB per wave-instruction - and kept a SECOND, row-major fp32 copy in
+// the screening sidecar for the re-scoring gathers: 2.5x the corpus in HBM.  Same-box A/B in round 4: the exact scan is
+// 1.1 % slower on this layout (54.93 -> 55.52 ms at 1 M x 10 k), the single-query path 3 % (0.328 -> 0.338 ms), and one
+// copy serves scan, re-scoring, save() and the bf16 conversion: 1.5x the corpus.)
+constexpr int STEP_FLOATS = 8;                // a k-step = the next 8 columns of the lane's row
+// float4 index, inside a 32-row tile, of chunk c (columns 4c .. 4c + 3) of row r
+__host__ __device__ inline int tile_idx4(int r, int c) { return r * (DIM / 4) + c; }
 
 // ------------------------------------------------------------------------- //
 // index add / get / normalise
@@ -50,17 +60,13 @@ __device__ inline int wave_sum_int(int v) {
   return v;
 }
 
-// One workgroup per tile. Rows go global(row-major) -> LDS -> global(tiled).
+// One workgroup per tile of 32 rows, one wave per 8 rows: copy (optionally x / ||x||), zero rows past n_rows.
 __global__ __launch_bounds__(256) void index_add_rows_kernel(
     const float4* __restrict__ rows, int64_t n_rows, int normalize, float4* __restrict__ tiled,
     int64_t dst_tile0) {
-  __shared__ float4 lds[TILE_ROWS * (CHUNKS + 1)];
-  __shared__ float inv_norm[TILE_ROWS];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row0 = (int64_t)blockIdx.x * TILE_ROWS;
-
-  // each wave owns 8 rows: coalesced float4 reads, norm by wave reduction
+  float4* out = tiled + (dst_tile0 + blockIdx.x) * (int64_t)(TILE_ROWS * CHUNKS);
   for (int rr = 0; rr < 8; ++rr) {
     const int r = wave * 8 + rr;
     const int64_t row = row0 + r;
@@ -72,18 +78,11 @@ __global__ __launch_bounds__(256) void index_add_rows_kernel(
     float ss = v0.x * v0.x + v0.y * v0.y + v0.z * v0.z + v0.w * v0.w;
     ss += v1.x * v1.x + v1.y * v1.y + v1.z * v1.z + v1.w * v1.w;
     ss = wave_sum(ss);
-    lds[r * (CHUNKS + 1) + lane] = v0;
-    if (lane < CHUNKS - 64) lds[r * (CHUNKS + 1) + 64 + lane] = v1;
-    if (lane == 0) inv_norm[r] = (normalize && ss > 0.f) ? 1.0f / sqrtf(ss) : 1.0f;
-  }
-  __syncthreads();
-  float4* out = tiled + (dst_tile0 + blockIdx.x) * (int64_t)(TILE_ROWS * CHUNKS);
-  for (int idx = tid; idx < TILE_ROWS * CHUNKS; idx += 256) {
-    const int c = idx >> 5, r = idx & 31;  // tiled order: chunk-major, row-minor
-    float4 v = lds[r * (CHUNKS + 1) + c];
-    const float s = inv_norm[r];
-    v.x *= s; v.y *= s; v.z *= s; v.w *= s;
-    out[idx] = v;
+    const float sc = (normalize && ss > 0.f) ? 1.0f / sqrtf(ss) : 1.0f;
+    v0.x *= sc; v0.y *= sc; v0.z *= sc; v0.w *= sc;
+    v1.x *= sc; v1.y *= sc; v1.z *= sc; v1.w *= sc;
+    out[r * CHUNKS + lane] = v0;
+    if (lane < CHUNKS - 64) out[r * CHUNKS + 64 + lane] = v1;
   }
 }
 
@@ -96,7 +95,7 @@ __global__ __launch_bounds__(256) void index_get_rows_kernel(const float4* __res
     const int64_t r = idx / CHUNKS;
     const int c = (int)(idx - r * CHUNKS);
     const int64_t row = row0 + r;
-    rows[idx] = tiled[(row >> 5) * (int64_t)(TILE_ROWS * CHUNKS) + c * 32 + (row & 31)];
+    rows[idx] = tiled[row * CHUNKS + c];
   }
 }
 
@@ -326,7 +325,7 @@ __global__ __launch_bounds__(WAVES * 64) void scan_topk_kernel(ScanParams p) {
 
   const int t_begin = slice * p.tiles_per_slice;
   const int t_end = min(t_begin + p.tiles_per_slice, p.n_tiles);
-  const float* lane_base = p.tiled + lane * 4;
+  const float* lane_base = p.tiled + (lane & 31) * DIM + 4 * (lane >> 5);   // row (lane & 31) of a tile, column half lane >> 5
   const bool ragged = (p.n_rows & 31) != 0;
 
   float4 bufA[GROUP], bufB[GROUP];
@@ -799,52 +798,34 @@ constexpr int SCREEN_FALLBACK_TIER1 = 1024;
 constexpr int SCREEN_LIGHT_MAX_TILES_PER_WAVE = 330;   // slices up to this length (500 k rows at 10 000 queries) keep their pools with one offer per lane and tile
 constexpr int SCREEN_CUS = 256;                  // MI355X: the launch geometry is planned in whole rounds of the chip
 
-// fp32 tiled corpus -> bf16 tiled corpus in A-operand order of v_mfma_f32_32x32x16_bf16:
-// tile t, step s, lane l holds row 32t + (l & 31), columns 16s + 8(l >> 5) + 0..7
-// Also writes the tile's 32 rows ROW-MAJOR in fp32 (rows_rm): the finalize kernel re-scores ~20 scattered
-// rows per query, and in the tiled layout a row is spread over 96 cache lines (16 useful bytes per 128-byte
-// line: 2.6 GB fetched for 0.3 GB used at the bench shape); row-major it is 12 whole lines.
-// column sums of the tiled fp32 index -> colsum[384] (pre-zeroed): block b walks tiles b, b + grid, ...; thread
-// tid owns float4 slots tid + 256 i of every tile (fixed lane, steps (tid >> 6) + 4 i), reduces over the 32 rows of
-// its half-wave and adds once per block.  Rows past n_rows are zero in the tiled layout.
+// fp32 index -> bf16 tiles of the CENTRED rows in A-operand order of v_mfma_f32_32x32x16_bf16:
+// tile t, step s, lane l holds row 32t + (l & 31), columns 16s + 8(l >> 5) + 0..7   (make_bf16_tiles_kernel below)
+// column sums of the fp32 index -> colsum[384] (pre-zeroed): block b walks tiles b, b + grid, ...
 __global__ __launch_bounds__(256) void tile_colsum_kernel(const float4* __restrict__ tiled, int64_t n_tiles,
                                                           float* __restrict__ colsum) {
-  float4 acc[12];
-#pragma unroll
-  for (int i = 0; i < 12; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // thread c < 96 of row group g (0 / 1) sums chunk c over the rows 2 i + g of its tiles (rows past n_rows are zero)
+  const int c = threadIdx.x % CHUNKS, g = threadIdx.x / CHUNKS;
+  if (g >= 2) return;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    const float4* src = tiled + t * (int64_t)(TILE_ROWS * CHUNKS) + threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      const float4 v = src[256 * i];
-      acc[i].x += v.x; acc[i].y += v.y; acc[i].z += v.z; acc[i].w += v.w;
+    const float4* src = tiled + t * (int64_t)(TILE_ROWS * CHUNKS);
+#pragma unroll 4
+    for (int r = g; r < TILE_ROWS; r += 2) {
+      const float4 v = src[r * CHUNKS + c];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
   }
-  const int l = threadIdx.x & 63;
-#pragma unroll
-  for (int i = 0; i < 12; ++i) {
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) {   // within a 32-lane half: same columns, different rows
-      acc[i].x += __shfl_xor(acc[i].x, o); acc[i].y += __shfl_xor(acc[i].y, o);
-      acc[i].z += __shfl_xor(acc[i].z, o); acc[i].w += __shfl_xor(acc[i].w, o);
-    }
-    if ((l & 31) == 0) {
-      const int u = (threadIdx.x >> 6) + 4 * i;            // step: columns 8 u + 4 (l >> 5) + 0..3
-      float* dst = colsum + 8 * u + 4 * (l >> 5);
-      atomicAdd(dst + 0, acc[i].x); atomicAdd(dst + 1, acc[i].y); atomicAdd(dst + 2, acc[i].z); atomicAdd(dst + 3, acc[i].w);
-    }
-  }
+  atomicAdd(colsum + 4 * c + 0, a.x); atomicAdd(colsum + 4 * c + 1, a.y);
+  atomicAdd(colsum + 4 * c + 2, a.z); atomicAdd(colsum + 4 * c + 3, a.w);
 }
 
 // norm block of the sidecar: ints [0..2] = max |c|^2, max |c~|^2, max |c~ - fl(c - mu)|^2 (bit patterns of
 // non-negative floats), floats [64 .. 64 + 384) = column sums, then the mean row
 constexpr int SIDECAR_NORM_BYTES = 4096;
 constexpr int SIDECAR_COLSUM_OFF = 64;   // in floats
-constexpr int SIDECAR_HAS_ROWS_WORD = 8; // int [8]: 1 = the row-major fp32 rows follow the norm block, 0 = compact sidecar
 
 __global__ __launch_bounds__(256) void make_bf16_tiles_kernel(const float4* __restrict__ tiled, int64_t n_tiles, int64_t n_rows,
-                                                              sbf16x8* __restrict__ out, int* __restrict__ norm_block,
-                                                              float4* __restrict__ rows_rm) {
+                                                              sbf16x8* __restrict__ out, int* __restrict__ norm_block) {
   __shared__ float rowss[3][32];   // per row: |c|^2, |c~|^2, |c~ - fl(c - mu)|^2
   __shared__ float mu[DIM];
   const int64_t t = blockIdx.x;
@@ -856,7 +837,7 @@ __global__ __launch_bounds__(256) void make_bf16_tiles_kernel(const float4* __re
   for (int v = threadIdx.x; v < BTILE_VEC; v += 256) {
     const int sidx = v >> 6, l = v & 63, r = l & 31, hh = l >> 5;
     const int u = 2 * sidx + hh;
-    const float4 a = src[u * 64 + r], b = src[u * 64 + r + 32];
+    const float4 a = src[tile_idx4(r, 2 * u)], b = src[tile_idx4(r, 2 * u + 1)];
     const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     const bool live = t * TILE_ROWS + r < n_rows;   // padding rows stay all-zero (the kernel masks them anyway)
     sbf16x8 o;
@@ -872,11 +853,6 @@ __global__ __launch_bounds__(256) void make_bf16_tiles_kernel(const float4* __re
       dd = fmaf(d, d, dd);
     }
     out[t * BTILE_VEC + v] = o;
-    if (rows_rm) {   // (absent in a COMPACT sidecar: the finalize kernel then gathers from the fp32 tiles)
-      float4* const dst = rows_rm + (t * TILE_ROWS + r) * (int64_t)(DIM / 4) + 2 * u;  // columns 8u .. 8u + 7
-      dst[0] = a;
-      dst[1] = b;
-    }
     atomicAdd(&rowss[0][r], nn);
     atomicAdd(&rowss[1][r], bb);
     atomicAdd(&rowss[2][r], dd);
@@ -1284,9 +1260,7 @@ struct ScreenFinalAppendParams {
   const uint2* cand;          // [nq][lists][SCREEN_CAP]
   const int* cand_cnt;        // [nq][lists]
   const float* eps2;
-  const float* rows;          // fp32 rows, row-major (the sidecar's copy): exact re-scoring
-  const float4* tiled;        // the fp32 index tiles: what a COMPACT sidecar (no row-major copy) re-scores from
-  const int* norm_block;      // the sidecar's norm block: word SIDECAR_HAS_ROWS_WORD says which of the two to read
+  const float* rows;          // the fp32 index itself (row-major): exact re-scoring
   const float* queries;
   int lists, k, nq;
   int64_t id_offset;
@@ -1462,10 +1436,7 @@ __global__ __launch_bounds__(64) void screen_finalize_append_kernel(ScreenFinalA
   __builtin_amdgcn_s_waitcnt(0xC07F);
 
   // exact scores, 64 candidates per round: the fma order of the 32x32x2 f32 MFMA chain (section 3.1).
-  // Rows come from the sidecar's row-major copy (a row = 12 whole cache lines) or, with a COMPACT sidecar, from the fp32
-  // tiles themselves: element (row, step u, half hb) is float4 (tile 48 + u) 64 + (row & 31) + 32 hb - 96 lines of
-  // which 16 bytes each are used, the price of keeping one fp32 copy instead of two.
-  const bool rows_rm = __builtin_amdgcn_readfirstlane(p.norm_block[SIDECAR_HAS_ROWS_WORD]) != 0;
+  // A candidate row = 12 whole cache lines of the index.
   float cs[SCREEN_MAX_CAND / 64];
   int cid[SCREEN_MAX_CAND / 64];
 #pragma unroll
@@ -1475,13 +1446,11 @@ __global__ __launch_bounds__(64) void screen_finalize_append_kernel(ScreenFinalA
     const int idx = c * 64 + lane;
     if (idx < M) {
       const int row = ci[idx];
-      const float4* src = rows_rm ? reinterpret_cast<const float4*>(p.rows) + (int64_t)row * (DIM / 4)
-                                  : p.tiled + (int64_t)(row >> 5) * (TILE_ROWS * CHUNKS) + (row & 31);
-      const int su = rows_rm ? 2 : 64, sh = rows_rm ? 1 : 32;   // float4 strides of a step / of its second half
+      const float4* src = reinterpret_cast<const float4*>(p.rows) + (int64_t)row * (DIM / 4);
       float acc = 0.f;
 #pragma unroll 16
       for (int u = 0; u < STEPS; ++u) {  // 16 steps = four whole 128-byte lines of the row in flight
-        const float4 a = src[su * u], b = src[su * u + sh];
+        const float4 a = src[2 * u], b = src[2 * u + 1];
         const float4 qa = *reinterpret_cast<const float4*>(&qv[8 * u]), qb = *reinterpret_cast<const float4*>(&qv[8 * u + 4]);
         acc = fmaf(a.x, qa.x, acc); acc = fmaf(b.x, qb.x, acc);
         acc = fmaf(a.y, qa.y, acc); acc = fmaf(b.y, qb.y, acc);
@@ -2197,47 +2166,29 @@ ScreenWs screen_carve(void* base, const ScreenPlan& pl, int64_t n_rows, int nq, 
 }
 }  // namespace
 
-// screening sidecar: [bf16 tiles of the CENTRED rows][4 KiB: norm maxima + column sums][fp32 rows, row-major (re-scoring gathers)]
+// screening sidecar: [bf16 tiles of the CENTRED rows][4 KiB: norm maxima + column sums]   (exact re-scoring reads the index itself)
 static inline size_t sidecar_norm_offset(int64_t n_rows) { return (size_t)sskd::ceil_div(n_rows, TILE_ROWS) * BTILE_VEC * 16; }
 static inline size_t sidecar_rows_offset(int64_t n_rows) { return sidecar_norm_offset(n_rows) + SIDECAR_NORM_BYTES; }
 
 size_t sskd_index_bf16_bytes(int64_t n_rows) {
   if (n_rows <= 0) return 0;
-  return sidecar_rows_offset(n_rows) + (size_t)sskd_index_padded_rows(n_rows) * DIM * sizeof(float);
-}
-
-size_t sskd_index_bf16_bytes_compact(int64_t n_rows) {
-  if (n_rows <= 0) return 0;
   return sidecar_rows_offset(n_rows);
 }
 
-static int make_bf16_impl(const float* d_tiled, int64_t n_rows, void* d_bf16, void* stream, bool with_rows);
-
 int sskd_index_make_bf16(const float* d_tiled, int64_t n_rows, void* d_bf16, void* stream) {
-  return make_bf16_impl(d_tiled, n_rows, d_bf16, stream, true);
-}
-
-int sskd_index_make_bf16_compact(const float* d_tiled, int64_t n_rows, void* d_bf16, void* stream) {
-  return make_bf16_impl(d_tiled, n_rows, d_bf16, stream, false);
-}
-
-static int make_bf16_impl(const float* d_tiled, int64_t n_rows, void* d_bf16, void* stream, bool with_rows) {
   SSKD_REQUIRE(n_rows >= 0, "index_make_bf16: n_rows < 0");
   if (n_rows == 0) return SSKD_OK;
   SSKD_REQUIRE(d_tiled && d_bf16, "index_make_bf16: null pointer");
   hipStream_t st = sskd::as_stream(stream);
   const int64_t tiles = sskd::ceil_div(n_rows, TILE_ROWS);
   int* max_norm2 = reinterpret_cast<int*>(static_cast<char*>(d_bf16) + sidecar_norm_offset(n_rows));
-  float4* rows_rm = with_rows ? reinterpret_cast<float4*>(static_cast<char*>(d_bf16) + sidecar_rows_offset(n_rows)) : nullptr;
   if (hipMemsetAsync(max_norm2, 0, SIDECAR_NORM_BYTES, st) != hipSuccess) return sskd::fail(SSKD_ERR_HIP, "index_make_bf16: memset failed");
-  if (with_rows && hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(max_norm2 + SIDECAR_HAS_ROWS_WORD), 1, 1, st) != hipSuccess)
-    return sskd::fail(SSKD_ERR_HIP, "index_make_bf16: memset failed");
   hipLaunchKernelGGL(tile_colsum_kernel, dim3((unsigned)(tiles < 1024 ? tiles : 1024)), dim3(256), 0, st,
                      reinterpret_cast<const float4*>(d_tiled), tiles, reinterpret_cast<float*>(max_norm2) + SIDECAR_COLSUM_OFF);
   int rc = sskd::check_launch("tile_colsum_kernel");
   if (rc != SSKD_OK) return rc;
   hipLaunchKernelGGL(make_bf16_tiles_kernel, dim3((unsigned)tiles), dim3(256), 0, st,
-                     reinterpret_cast<const float4*>(d_tiled), tiles, n_rows, static_cast<sbf16x8*>(d_bf16), max_norm2, rows_rm);
+                     reinterpret_cast<const float4*>(d_tiled), tiles, n_rows, static_cast<sbf16x8*>(d_bf16), max_norm2);
   return sskd::check_launch("make_bf16_tiles_kernel");
 }
 
@@ -2327,9 +2278,7 @@ int sskd_index_search_screened(const float* d_tiled, const void* d_bf16, int64_t
   fp.cand = sp.cand;
   fp.cand_cnt = w.cand_cnt;
   fp.eps2 = w.eps2;
-  fp.rows = reinterpret_cast<const float*>(static_cast<const char*>(d_bf16) + sidecar_rows_offset(n_rows));   // (only read when the sidecar has them)
-  fp.tiled = reinterpret_cast<const float4*>(d_tiled);
-  fp.norm_block = max_norm2;
+  fp.rows = d_tiled;
   fp.queries = d_queries;
   fp.lists = pl.lists_per_query;
   fp.k = k;

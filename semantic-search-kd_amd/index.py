@@ -92,10 +92,7 @@ class FAISSIndexBuilder:
         # every query - no caller ever has to check a status), several times faster.
         # ``screening = False`` forces the plain exact scan.
         self.screening = True
-        # True: the screening sidecar keeps no second fp32 copy of the rows (768 B per row instead of 2 304: the index costs
-        # 1.5x the corpus instead of 2.5x); candidates are re-scored from the fp32 tiles - same bits, slower gathers
-        self.compact_sidecar = False
-        self._bf16: Optional[torch.Tensor] = None      # screening sidecar (bf16 tiles, max row norm, row-major fp32 rows), made lazily
+        self._bf16: Optional[torch.Tensor] = None      # screening sidecar (bf16 tiles of the centred rows + norm block: 768 B per row), made lazily
         self._bf16_rows = -1
         # device int32[2] of the last screened search: [0] always 0, [1] = queries that took the in-call
         # exact fallback (a cost diagnostic; nothing to act on)
@@ -261,11 +258,9 @@ class FAISSIndexBuilder:
             need = int(lib.sskd_index_search_screened_workspace_bytes(self._n, nq, k))
             if need:
                 if self._bf16 is None or self._bf16_rows != self._n:
-                    nbytes, make = ((lib.sskd_index_bf16_bytes_compact, lib.sskd_index_make_bf16_compact) if self.compact_sidecar
-                                    else (lib.sskd_index_bf16_bytes, lib.sskd_index_make_bf16))
                     self._bf16 = None
-                    self._bf16 = torch.empty(int(nbytes(self._n)), dtype=torch.uint8, device=self.device)
-                    _native.check(make(self._tiled.data_ptr(), self._n, self._bf16.data_ptr(), stream))
+                    self._bf16 = torch.empty(int(lib.sskd_index_bf16_bytes(self._n)), dtype=torch.uint8, device=self.device)
+                    _native.check(lib.sskd_index_make_bf16(self._tiled.data_ptr(), self._n, self._bf16.data_ptr(), stream))
                     self._bf16_rows = self._n
                 if self._workspace is None or self._workspace.numel() < need:
                     self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)

@@ -19,15 +19,11 @@ from semantic_search_kd_amd import FAISSIndexBuilder, _native
 pytestmark = pytest.mark.gpu
 
 
-def screened(lib, corpus, queries, k, id_offset=0, compact=False):
+def screened(lib, corpus, queries, k, id_offset=0):
     n, nq = corpus.shape[0], queries.shape[0]
     tiled = tile_corpus(lib, corpus)
-    if compact:   # sidecar without the row-major fp32 copy: candidates are re-scored from the tiles
-        bf = torch.empty(int(lib.sskd_index_bf16_bytes_compact(n)), dtype=torch.uint8, device="cuda")
-        _native.check(lib.sskd_index_make_bf16_compact(tiled.data_ptr(), n, bf.data_ptr(), stream()))
-    else:
-        bf = torch.empty(int(lib.sskd_index_bf16_bytes(n)), dtype=torch.uint8, device="cuda")
-        _native.check(lib.sskd_index_make_bf16(tiled.data_ptr(), n, bf.data_ptr(), stream()))
+    bf = torch.empty(int(lib.sskd_index_bf16_bytes(n)), dtype=torch.uint8, device="cuda")
+    _native.check(lib.sskd_index_make_bf16(tiled.data_ptr(), n, bf.data_ptr(), stream()))
     q = torch.from_numpy(np.ascontiguousarray(queries, np.float32)).cuda()
     out_s = torch.full((nq, k), float("nan"), device="cuda")
     out_i = torch.full((nq, k), -7, dtype=torch.int64, device="cuda")
@@ -488,25 +484,16 @@ def test_screened_topic_sorted_corpus_at_the_bench_geometry(gpu, native_lib):
     assert torch.equal(out_i, ex_i) and torch.equal(out_s, ex_s)
 
 
-@pytest.mark.parametrize("n,nq,k", [(2049, 65, 10), (20011, 257, 7), (100000, 1000, 10)])
-def test_compact_sidecar_equals_exact_bits(gpu, native_lib, n, nq, k):
-    """The COMPACT sidecar (bf16 tiles + norms, 768 B per row: no second fp32 copy of the rows) re-scores its candidates
-    from the fp32 tiles: the same bits as the oracle, ragged last tile and id offset included; and 2 304 - 768 = 1 536
-    bytes per row smaller.  Through the product class too (``compact_sidecar = True``)."""
-    corpus = oracle.seeded_unit_rows(n, 384, 300 + n % 89)
-    queries = oracle.seeded_unit_rows(nq, 384, 400 + nq)
-    for i in range(0, nq, 5):
-        queries[i] = corpus[(i * 41) % n] + 0.05 * queries[i]
-        queries[i] /= np.linalg.norm(queries[i])
-    s, i, st = screened(native_lib, corpus, queries, k, id_offset=77, compact=True)
-    ref_s, ref_i = oracle.topk_fma(queries, corpus, k, 77)
-    assert st[0] == 0 and np.array_equal(i, ref_i) and np.array_equal(s, ref_s)
-    padded = int(native_lib.sskd_index_padded_rows(n))
-    assert int(native_lib.sskd_index_bf16_bytes(n)) - int(native_lib.sskd_index_bf16_bytes_compact(n)) == padded * 1536
-    index = FAISSIndexBuilder(embedding_dim=384, metric="ip", device="cuda:0", id_offset=77)
-    index.compact_sidecar = True
-    index.add(corpus)
-    hs, hi = index.search(queries, k)
-    assert index.last_search_path.endswith("+screened") or nq < 64
-    assert np.array_equal(hi, ref_i) and np.array_equal(hs, ref_s)
-    assert index._bf16 is None or index._bf16.numel() == int(native_lib.sskd_index_bf16_bytes_compact(n))
+def test_index_is_one_row_major_copy_and_the_sidecar_holds_no_second_one(gpu, native_lib):
+    """Round 4: the index is the plain row-major fp32 matrix (zero-padded to 32 rows) and serves scan, exact
+    re-scoring and save(); the screening sidecar is the bf16 tiles + a 4-KiB norm block - index + sidecar = 1.5x the
+    corpus (rounds 2-3: 2.5x, a second fp32 copy lived in the sidecar)."""
+    lib = native_lib
+    for n in (32, 2049, 1_000_000, 8_841_823):
+        padded = int(lib.sskd_index_padded_rows(n))
+        assert int(lib.sskd_index_tiled_bytes(n)) == padded * 1536
+        assert int(lib.sskd_index_bf16_bytes(n)) == padded * 768 + 4096
+    corpus = oracle.seeded_unit_rows(2049, 384, 9)
+    buf = tile_corpus(lib, corpus)
+    got = buf.cpu().numpy().reshape(-1, 384)
+    assert got.shape[0] == 2080 and np.array_equal(got[:2049], corpus) and not got[2049:].any()

@@ -35,14 +35,8 @@ for path in sys.argv[1:]:
         fn.restype, fn.argtypes = _native.SIGNATURES[n]
     tiled = torch.empty(int(lib.sskd_index_tiled_bytes(N)) // 4, dtype=torch.float32, device=dev)
     assert lib.sskd_index_add_rows(corpus.data_ptr(), N, 0, tiled.data_ptr(), 0, st) == 0
-    if os.environ.get("AB_COMPACT"):   # the sidecar without its row-major fp32 copy
-        for n in ("sskd_index_bf16_bytes_compact", "sskd_index_make_bf16_compact"):
-            getattr(lib, n).restype, getattr(lib, n).argtypes = _native.SIGNATURES[n]
-        bf = torch.empty(int(lib.sskd_index_bf16_bytes_compact(N)), dtype=torch.uint8, device=dev)
-        assert lib.sskd_index_make_bf16_compact(tiled.data_ptr(), N, bf.data_ptr(), st) == 0
-    else:
-        bf = torch.empty(int(lib.sskd_index_bf16_bytes(N)), dtype=torch.uint8, device=dev)
-        assert lib.sskd_index_make_bf16(tiled.data_ptr(), N, bf.data_ptr(), st) == 0
+    bf = torch.empty(int(lib.sskd_index_bf16_bytes(N)), dtype=torch.uint8, device=dev)
+    assert lib.sskd_index_make_bf16(tiled.data_ptr(), N, bf.data_ptr(), st) == 0
     ws = torch.empty(int(lib.sskd_index_search_workspace_bytes(N, NQ, K) if EXACT else
                          lib.sskd_index_search_screened_workspace_bytes(N, NQ, K)), dtype=torch.uint8, device=dev)
     libs.append((Path(path).stem, lib, tiled, bf, ws))
