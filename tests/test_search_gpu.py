@@ -29,22 +29,29 @@ def _check_exact(lib, corpus, queries, k, id_offset=0):
     return s, i
 
 
-def test_tiled_layout_roundtrip_is_bit_exact(gpu, native_lib):
+def test_index_layout_roundtrip_is_bit_exact(gpu, native_lib):
     for n in (1, 31, 32, 33, 1000, 4099):
         x = oracle.seeded_unit_rows(n, 384, 7 + n)
         tiled = tile_corpus(native_lib, x)
         back = torch.empty((n, 384), dtype=torch.float32, device="cuda")
         _native.check(native_lib.sskd_index_get_rows(tiled.data_ptr(), 0, n, back.data_ptr(), stream()))
         assert np.array_equal(back.cpu().numpy(), x)
-        # documented layout: tile t, step u, lane l -> row 32t + (l & 31), cols 8u + 4(l >> 5) + e
-        t = tiled.cpu().numpy()[: ((n + 31) // 32) * 32 * 384].reshape(-1, 48, 64, 4)
-        for row, u, h in ((0, 0, 0), (n - 1, 47, 1), (n // 2, 13, 1), (n // 3, 30, 0)):
-            lane = row % 32 + 32 * h
-            assert np.array_equal(t[row // 32, u, lane], x[row, 8 * u + 4 * h + np.arange(4)])
-        # padding rows are zero
-        if n % 32:
-            pad = t[-1].reshape(48, 2, 32, 4)[:, :, n % 32 :, :]
-            assert not pad.any()
+        # documented layout (round 4): the plain row-major matrix, zero-padded to a multiple of 32 rows
+        padded = ((n + 31) // 32) * 32
+        t = tiled.cpu().numpy()[: padded * 384].reshape(padded, 384)
+        assert np.array_equal(t[:n], x)
+        assert not t[n:].any()
+        # a sub-range read back from the middle
+        if n > 40:
+            part = torch.empty((7, 384), dtype=torch.float32, device="cuda")
+            _native.check(native_lib.sskd_index_get_rows(tiled.data_ptr(), 33, 7, part.data_ptr(), stream()))
+            assert np.array_equal(part.cpu().numpy(), x[33:40])
+    # normalising add: x / ||x||, zero rows untouched (faiss.normalize_L2)
+    x = oracle.seeded_unit_rows(70, 384, 3) * np.linspace(0.1, 9.0, 70, dtype=np.float32)[:, None]
+    x[5] = 0
+    t = tile_corpus(native_lib, x, normalize=True).cpu().numpy()[: 96 * 384].reshape(96, 384)
+    want = oracle.l2_normalize_rows(x)
+    assert np.allclose(t[:70], want, rtol=0, atol=2e-7) and not t[5].any() and not t[70:].any()
 
 
 def test_conftest_recipe_10_docs(gpu, native_lib):
