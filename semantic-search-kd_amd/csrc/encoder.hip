@@ -442,6 +442,31 @@ struct MlpParams {
 
 constexpr int MLP_CHUNKS = FF / 32;  // 48
 
+// One wave-level 1-KiB store as FOUR ds_write_addtid_b32 (address = M0 + offset + 4 lane, no address register, 2 cycles
+// each: 128 B/clk/CU against ~79 for ds_write_b128, whose VGPR -> LDS transfer is what the producers' burst queues on).
+// Plane k of the region holds dword k of every lane's vector: the weight images are permuted on the host
+// (weights.permute_for_addtid) so that a lane-linear ds_read_b128 of the region still returns each lane's fragment.
+// `base` = LDS byte offset of the 1-KiB region, wave-uniform; M0 carries 16 bits, the immediate the rest.
+#ifdef SSKD_MLP_ADDTID
+__device__ inline void lds_store_addtid4(unsigned base, const bf16x8& v) {
+  const u32x4 d = __builtin_bit_cast(u32x4, v);
+  if (base < 65536u) {
+    asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                 "ds_write_addtid_b32 %0\n\tds_write_addtid_b32 %1 offset:256\n\t"
+                 "ds_write_addtid_b32 %2 offset:512\n\tds_write_addtid_b32 %3 offset:768"
+                 :: "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "s"(base) : "memory");
+  } else {
+    asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                 "ds_write_addtid_b32 %0 offset:49152\n\tds_write_addtid_b32 %1 offset:49408\n\t"
+                 "ds_write_addtid_b32 %2 offset:49664\n\tds_write_addtid_b32 %3 offset:49920"
+                 :: "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "s"(base - 49152u) : "memory");
+  }
+}
+__device__ inline unsigned lds_offset_of(const void* p) {
+  return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p);
+}
+#endif
+
 __device__ inline void glds16(const void* g, void* l) {   // LDS-DMA: 16 B per lane, global -> LDS, no registers
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
@@ -611,14 +636,22 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
           // the bias as the first MFMA's C operand: +0.7 %; a 5-VALU GELU (pre-scaled weights): -0.4 %.
 #if !defined(SSKD_MLP_ABL_NOSTAGE) && !defined(SSKD_MLP_DMA)   // timing ablations (tools/ab_build.py): results wrong
           if (s % 4 == 1) {
+#ifdef SSKD_MLP_ADDTID
+            lds_store_addtid4(lds_offset_of(d1 - lane + 256 * (s / 4)), st1[s / 4]);
+#else
             d1[256 * (s / 4)] = st1[s / 4];
+#endif
 #ifndef SSKD_MLP_ABL_NOSTAGE_LOADS
             st1[s / 4] = s1[256 * (s / 4)];
 #endif
           }
 #ifndef SSKD_MLP_W2_IN_P2
           if (s % 4 == 3) {
+#ifdef SSKD_MLP_ADDTID
+            lds_store_addtid4(lds_offset_of(d2 - lane + 256 * (s / 4)), st2[s / 4]);
+#else
             d2[256 * (s / 4)] = st2[s / 4];
+#endif
 #ifndef SSKD_MLP_ABL_NOSTAGE_LOADS
             st2[s / 4] = s2[256 * (s / 4)];
 #endif
