@@ -633,7 +633,9 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
           // LDS-DMA, six pieces per wave and chunk issued at the start of each role's vector phase with counted vmcnt
           // (-DSSKD_MLP_DMA, bit-identical results): 7.36 vs 6.90 ms (+6.8 %: a DMA piece costs its wave more issue time
           // than {load, ds_write_b128}); the W2 half moved to the producers' vector phase (-DSSKD_MLP_W2_IN_P2): +2.9 %;
-          // the bias as the first MFMA's C operand: +0.7 %; a 5-VALU GELU (pre-scaled weights): -0.4 %.
+          // the bias as the first MFMA's C operand: +0.7 %; a 5-VALU GELU (pre-scaled weights): -0.4 %; every 1-KiB store as four
+          // ds_write_addtid_b32 (2 cycles each, no address register; -DSSKD_MLP_ADDTID, timing build): 7.59 vs 6.94 ms (+9 %:
+          // four LDS instructions + the M0 set-up cost the in-order wave more than one ds_write_b128).
 #if !defined(SSKD_MLP_ABL_NOSTAGE) && !defined(SSKD_MLP_DMA)   // timing ablations (tools/ab_build.py): results wrong
           if (s % 4 == 1) {
 #ifdef SSKD_MLP_ADDTID
