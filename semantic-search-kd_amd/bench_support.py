@@ -254,7 +254,14 @@ def bench_kd_step(device, tuples: int = 32, docs_per_query: int = 8, q_len: int 
 
     cfg = BertConfig()
     model = TrainableEncoder(cfg, synthetic_state_dict(cfg), device)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-5)
+    # torch.optim.AdamW as the reference uses it (src/kd/train.py:131-135), in its fused form: one pass over the 33 M
+    # parameters instead of ~10 foreach passes (~1.5 ms of a 30 ms step)
+    opt_kw = {"fused": True}
+    try:
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-5, **opt_kw)
+    except (RuntimeError, TypeError, ValueError):
+        opt_kw = {}
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-5)
     loss_fn = CombinedKDLoss()
     q_ids, q_mask = synthetic_ids(tuples, q_len, cfg.vocab_size, device, seed=1)
     d_ids, d_mask = synthetic_ids(tuples * docs_per_query, d_len, cfg.vocab_size, device, seed=2)
@@ -285,7 +292,7 @@ def bench_kd_step(device, tuples: int = 32, docs_per_query: int = 8, q_len: int 
     try:
         from .training import GraphedStep
 
-        opt = torch.optim.AdamW(model.parameters(), lr=1e-5, capturable=True)
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-5, capturable=True, **opt_kw)
         graphed = GraphedStep(step, warmup=2)
         graphed()
         torch.cuda.synchronize()
@@ -303,6 +310,7 @@ def bench_kd_step(device, tuples: int = 32, docs_per_query: int = 8, q_len: int 
         "unit": "tuples/s",
         "ms_per_step": round(dt * 1e3, 3),
         "launch_mode": "hip graph replay (one graph per step)" if graph_note is None else "eager",
+        "optimizer": "torch.optim.AdamW(fused=True)" if opt_kw else "torch.optim.AdamW",
         "ms_per_step_eager": round(dt_eager * 1e3, 3),
         "graph_note": graph_note,
         "dtype": "bf16",
