@@ -526,8 +526,16 @@ struct AttnArgs {
   float scale2; // scale * log2(e)
 };
 
-__device__ inline float pair_max32(float v) { return fmaxf(v, __shfl_xor(v, 32)); }
-__device__ inline float pair_sum32(float v) { return v + __shfl_xor(v, 32); }
+// exchange with lane ^ 32 in the VALU (v_permlane32_swap) instead of __shfl_xor's ds_bpermute: that is an LDS round trip
+// in the middle of the per-key-tile dependency chain (score MFMA -> max -> exchange -> exp -> PV MFMA)
+__device__ inline float pair_max32(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ inline float pair_sum32(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 // Row-major [key][DH] bf16 image of a head's V in LDS, read TRANSPOSED.  Byte offset of 16-byte chunk c of key k:
 // k * 2 DH + (16 c ^ att_vswz(k)).  The XOR moves whole 64-byte groups of a row so that the four key rows of one
@@ -569,6 +577,7 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnArgs p) {
   bf16_t* const vl = reinterpret_cast<bf16_t*>(kl + (size_t)p.nkt * KS * 64);   // [nkt][DT][2][64][8]
   float* const mb = reinterpret_cast<float*>(vl + (size_t)p.S * DH);            // [S] additive key bias
   __shared__ int s_kmax;
+  __shared__ int s_partial[16];   // key tile holds a masked key (S <= 512)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, h = lane >> 5;
@@ -580,11 +589,13 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnArgs p) {
   const bf16_t* base = p.qkv + row0 * ld + (int64_t)head * DH;
 
   if (tid == 0) s_kmax = 0;
+  if (tid < 16) s_partial[tid] = 0;
   __syncthreads();
   for (int i = tid; i < p.S; i += 512) {
     const bool on = p.mask[row0 + i] != 0;
     mb[i] = on ? 0.f : ATT_NEG;
     if (on) atomicMax(&s_kmax, i / 32 + 1);
+    else s_partial[i >> 5] = 1;
   }
   // K: 16-byte pieces straight into fragment order
   constexpr int CPK = DH / 8;  // 8-element chunks per key
@@ -621,15 +632,26 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnArgs p) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl[(kt * KS + s) * 64 + lane], qf[s], sc, 0, 0, 0);
     // sc[4g + e] = score(key 32 kt + 8g + 4h + e, query = lane & 31)
+    // Key tiles without a masked key (all of them on full-length rows) skip the bias: the maximum is taken on the RAW
+    // scores (scale2 > 0 is monotone) and the scale rides in the exponent's fma, exp2(sc scale2 - m): 16 multiplies and
+    // four LDS reads fewer per tile and lane.  m, l and the saved log-sum-exp stay in scaled (log2) units.
     float mt = ATT_NEG;
+    const bool clean = s_partial[kt] == 0;   // workgroup-uniform
+    if (clean) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 bias = *reinterpret_cast<const float4*>(&mb[kt * 32 + 8 * g + 4 * h]);
-      sc[4 * g + 0] = fmaf(sc[4 * g + 0], p.scale2, bias.x);
-      sc[4 * g + 1] = fmaf(sc[4 * g + 1], p.scale2, bias.y);
-      sc[4 * g + 2] = fmaf(sc[4 * g + 2], p.scale2, bias.z);
-      sc[4 * g + 3] = fmaf(sc[4 * g + 3], p.scale2, bias.w);
-      mt = fmaxf(fmaxf(fmaxf(mt, sc[4 * g + 0]), fmaxf(sc[4 * g + 1], sc[4 * g + 2])), sc[4 * g + 3]);
+      for (int g = 0; g < 4; ++g)
+        mt = fmaxf(fmaxf(fmaxf(mt, sc[4 * g + 0]), fmaxf(sc[4 * g + 1], sc[4 * g + 2])), sc[4 * g + 3]);
+      mt *= p.scale2;
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 bias = *reinterpret_cast<const float4*>(&mb[kt * 32 + 8 * g + 4 * h]);
+        sc[4 * g + 0] = fmaf(sc[4 * g + 0], p.scale2, bias.x);
+        sc[4 * g + 1] = fmaf(sc[4 * g + 1], p.scale2, bias.y);
+        sc[4 * g + 2] = fmaf(sc[4 * g + 2], p.scale2, bias.z);
+        sc[4 * g + 3] = fmaf(sc[4 * g + 3], p.scale2, bias.w);
+        mt = fmaxf(fmaxf(fmaxf(mt, sc[4 * g + 0]), fmaxf(sc[4 * g + 1], sc[4 * g + 2])), sc[4 * g + 3]);
+      }
     }
     mt = pair_max32(mt);
     if (__any(mt > m)) {
@@ -644,9 +666,10 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnArgs p) {
     }
     bf16x8 pf[2];
     float ps = 0.f;
+    const float es = clean ? p.scale2 : 1.0f;   // scores still raw on clean tiles
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const float e = __builtin_amdgcn_exp2f(sc[i] - m);
+      const float e = __builtin_amdgcn_exp2f(fmaf(sc[i], es, -m));
       ps += e;
       pf[i >> 3][i & 7] = (bf16_t)e;
     }
