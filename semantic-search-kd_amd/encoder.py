@@ -210,7 +210,7 @@ class Mi355xSentenceEncoder:
             from .training import TrainableEncoder
 
             self._trainable = TrainableEncoder(self.config, self._host_state, self.device)
-            self._trainable_versions = tuple(p._version for p in self._trainable.parameters())
+            self._trainable_versions = (self._trainable._epoch,) + tuple(p._version for p in self._trainable.parameters())
         return self._trainable
 
     def parameters(self):
@@ -236,7 +236,7 @@ class Mi355xSentenceEncoder:
         (called by ``encode`` so that evaluation after optimizer steps sees the new weights)."""
         if self._trainable is None:
             return False
-        versions = tuple(p._version for p in self._trainable.parameters())
+        versions = (self._trainable._epoch,) + tuple(p._version for p in self._trainable.parameters())
         if versions == self._trainable_versions:
             return False
         self._host_state = self._trainable.state_dict_numpy()

@@ -153,6 +153,7 @@ class TrainableEncoder(nn.Module):
             float(config.layer_norm_eps), pos_offset)
         self._weights_version = -1
         self._seen_versions: Optional[tuple] = None
+        self._epoch = 0   # bumped by invalidate(): changes that torch's version counters do not see (HIP-graph replays)
         self._keep: list = []
         self.w_struct = None
         self.g_struct, self._g_layers = self._grad_struct()
@@ -188,8 +189,10 @@ class TrainableEncoder(nn.Module):
     def invalidate(self) -> None:
         """Force the bf16 copies to be rebuilt at the next forward.  Needed only after parameters were changed through
         ``p.data`` / ``torch.no_grad`` tricks that do not bump the tensors' version counters (in-place optimizer steps
-        do bump them and are picked up automatically)."""
+        do bump them and are picked up automatically) - and after REPLAYING a captured training step (GraphedStep): a
+        replay updates the parameters on the device without touching torch's counters."""
         self._seen_versions = None
+        self._epoch += 1
 
     def _refresh_device_weights(self) -> None:
         params = list(self.parameters())
@@ -321,9 +324,14 @@ class GraphedStep:
     ``opt.zero_grad(set_to_none=True)`` inside ``step_fn`` is fine: the gradient views are re-attached during capture
     and the memset of the flat gradient buffer is part of the graph."""
 
-    def __init__(self, step_fn, warmup: int = 3) -> None:
+    def __init__(self, step_fn, warmup: int = 3, modules: Sequence["TrainableEncoder"] = ()) -> None:
+        """``modules``: the ``TrainableEncoder``s the step trains.  A replay changes their parameters without bumping
+        torch's version counters, so every replay marks them stale (``invalidate()``): the next EAGER forward - an
+        evaluation between steps, ``Mi355xSentenceEncoder.encode`` - then re-casts the weights instead of using the bf16
+        copies of one optimizer step ago."""
         _native.require_gpu()
         self._fn = step_fn
+        self._modules = list(modules)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):          # warm-up off the default stream, as torch's capture rules ask
@@ -339,6 +347,8 @@ class GraphedStep:
     def __call__(self):
         self.graph.replay()
         self.steps_replayed += 1
+        for m in self._modules:
+            m.invalidate()
         return self.out
 
     @staticmethod

@@ -357,7 +357,7 @@ def test_graphed_kd_step_replays_the_eager_step(gpu):
         if graphed:
             # the capture's two warm-up steps train on batch 0 (the captured step itself is only recorded, not run):
             # the eager arm takes the same two steps
-            runner = GraphedStep(step, warmup=2)
+            runner = GraphedStep(step, warmup=2, modules=[model])
         else:
             for _ in range(2):
                 step()
@@ -365,11 +365,15 @@ def test_graphed_kd_step_replays_the_eager_step(gpu):
         for b in batches:
             GraphedStep.copy_inputs(static, b)
             losses.append(float(runner()))
+        # an EAGER forward after the replays must see the trained weights (a replay does not bump torch's version
+        # counters: GraphedStep(modules=...) marks the bf16 device copies stale instead)
+        emb = model(batches[0][0], batches[0][1]).detach().cpu().numpy()
         torch.cuda.synchronize()
-        return losses, {n: model.p(n).detach().cpu().numpy().copy() for n in model.names}
+        return losses, {n: model.p(n).detach().cpu().numpy().copy() for n in model.names}, emb
 
-    eager_losses, eager_params = run(False)
-    graph_losses, graph_params = run(True)
+    eager_losses, eager_params, eager_emb = run(False)
+    graph_losses, graph_params, graph_emb = run(True)
+    assert np.abs(eager_emb - graph_emb).max() < 5e-3, np.abs(eager_emb - graph_emb).max()
     assert np.allclose(eager_losses, graph_losses, rtol=1e-3, atol=1e-4), (eager_losses, graph_losses)
     assert eager_losses[-1] != eager_losses[0]
     # Parameters: AdamW moves a weight by ~lr per step whatever the size of its gradient, so a weight whose gradient is
