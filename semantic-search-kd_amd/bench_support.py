@@ -355,11 +355,35 @@ def bench_teacher(device, world: int, steps: int, warmup: int, barrier, pairs: i
     h, f = cfg.hidden_size, cfg.intermediate_size
     flops = pairs * seq_len * cfg.num_hidden_layers * (2.0 * (4 * h * h + 2 * h * f) + 4.0 * seq_len * h)
     tf = flops * steps / dt / 1e12
+    # the same step with every product on this repo's own MFMA kernels (sskd_gemm_backend(1)): what the hand-written
+    # path alone delivers, beside the default in which the three plain products of a layer go through hipBLASLt
+    own = None
+    if world == 1:
+        from . import _native
+
+        lib = _native.load()
+        try:
+            lib.sskd_gemm_backend(1)
+            teacher.score_token_ids(ids, mask, out=out)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(max(2, steps // 2)):
+                teacher.score_token_ids(ids, mask, out=out)
+            torch.cuda.synchronize()
+            dt_own = (time.perf_counter() - t0) / max(2, steps // 2)
+        finally:
+            lib.sskd_gemm_backend(0)
     text = bench_teacher_text(teacher) if (world == 1 or dist.get_rank() == 0) else None
+    h, f = cfg.hidden_size, cfg.intermediate_size
+    if world == 1:
+        flops1 = pairs * seq_len * cfg.num_hidden_layers * (2.0 * (4 * h * h + 2 * h * f) + 4.0 * seq_len * h)
+        own = {"ms_per_step": round(dt_own * 1e3, 3), "mfma_bf16_frac": round(flops1 / dt_own / 1e12 / MFMA_BF16_PEAK_TF, 4)}
     return {
         "value": round(world * pairs * steps / dt, 1),
         "unit": "pairs/s",
         "ms_per_step": round(dt / steps * 1e3, 3),
+        "gemm_backend": "QKV / attention output / FFN2: hipBLASLt (plain products); FFN1 + erf-GELU, attention, LayerNorm, head: this repo's kernels",
+        "own_kernels_only": own,
         "dtype": "bf16",
         "workload": f"XLM-R-large-shaped cross-encoder, {pairs} pairs x {seq_len} tokens per GPU per step, random-init weights",
         "finite": bool(torch.isfinite(out).all()),
