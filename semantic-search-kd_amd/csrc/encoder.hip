@@ -431,7 +431,8 @@ struct MlpParams {
   const bf16x8* x1;      // fragment-order [T_pad, 384]: GEMM input and residual
   const bf16x8* w1;      // tiled [48][24][64]: chunk c = features 32c..32c+31 of W1 [1536, 384]
   const float* b1;       // [1536]
-  const bf16x8* w2c;     // chunk-major [48][12][2][64]: W2[32 nt + r][32 c + 16 s2 + 8 h + j]
+  const bf16x8* w2p;     // chunk-major [48][12][2][64]: lane l, slot j of fragment (c, nt, s2) =
+                         // W2[32 nt + (l & 31)][32 c + 16 s2 + 8 (j >> 2) + 4 (l >> 5) + (j & 3)]  (weights.tile_w2_chunked)
   const float* b2;       // [384]
   const float* gamma;
   const float* beta;
@@ -440,39 +441,10 @@ struct MlpParams {
   GemmN384Params outp;   // FUSE_OUTPROJ: X1 = LN(X + ctx Wo^T + bo) is computed in the prologue
 };
 
-constexpr int MLP_CHUNKS = FF / 32;  // 48
+constexpr int MLP_SUPER = FF / 128;  // 12 super-chunks of 128 hidden units
 
-// One wave-level 1-KiB store as FOUR ds_write_addtid_b32 (address = M0 + offset + 4 lane, no address register, 2 cycles
-// each: 128 B/clk/CU against ~79 for ds_write_b128, whose VGPR -> LDS transfer is what the producers' burst queues on).
-// Plane k of the region holds dword k of every lane's vector: the weight images are permuted on the host
-// (weights.permute_for_addtid) so that a lane-linear ds_read_b128 of the region still returns each lane's fragment.
-// `base` = LDS byte offset of the 1-KiB region, wave-uniform; M0 carries 16 bits, the immediate the rest.
-#ifdef SSKD_MLP_ADDTID
-__device__ inline void lds_store_addtid4(unsigned base, const bf16x8& v) {
-  const u32x4 d = __builtin_bit_cast(u32x4, v);
-  if (base < 65536u) {
-    asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\t"
-                 "ds_write_addtid_b32 %0\n\tds_write_addtid_b32 %1 offset:256\n\t"
-                 "ds_write_addtid_b32 %2 offset:512\n\tds_write_addtid_b32 %3 offset:768"
-                 :: "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "s"(base) : "memory");
-  } else {
-    asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\t"
-                 "ds_write_addtid_b32 %0 offset:49152\n\tds_write_addtid_b32 %1 offset:49408\n\t"
-                 "ds_write_addtid_b32 %2 offset:49664\n\tds_write_addtid_b32 %3 offset:49920"
-                 :: "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "s"(base - 49152u) : "memory");
-  }
-}
-__device__ inline unsigned lds_offset_of(const void* p) {
-  return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p);
-}
-#endif
-
-__device__ inline void glds16(const void* g, void* l) {   // LDS-DMA: 16 B per lane, global -> LDS, no registers
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-}
-#ifndef SSKD_MLP_PF
-#define SSKD_MLP_PF 6
+#ifndef SSKD_MLP_XR
+#define SSKD_MLP_XR 6   // ring of X1 fragments in the producers' burst (XR - 1 LDS reads in flight)
 #endif
 
 #ifdef SSKD_PROBE
@@ -480,7 +452,7 @@ __device__ inline void glds16(const void* g, void* l) {   // LDS-DMA: 16 B per l
 __device__ unsigned long long g_probe[2][64][4];
 #define SSKD_STAMP(role, it, slot)                                                         \
   do {                                                                                     \
-    if (blockIdx.x == 0 && tg == 0 && (it) < 64) {                                         \
+    if (blockIdx.x == 0 && pq == 0 && (it) < 64) {                                         \
       __builtin_amdgcn_sched_barrier(0);                                                   \
       unsigned long long t_ = __builtin_amdgcn_s_memtime();                                \
       __builtin_amdgcn_s_waitcnt(0xC07F);                                                  \
@@ -492,367 +464,319 @@ __device__ unsigned long long g_probe[2][64][4];
 #define SSKD_STAMP(role, it, slot) do {} while (0)
 #endif
 
-// Workgroup = 8 waves = 128 tokens.  Waves 0-3 are PRODUCERS (hT = W1 X1^T, X1 in 96 registers),
-// waves 4-7 CONSUMERS (Y^T += W2 hT, 192 accumulators); wave w and w + 4 own the same 32-token
-// tile and (waves of a workgroup are dealt to SIMDs cyclically) share a SIMD.
+// 16 B per lane through a buffer resource: wave-uniform fragment offset in an SGPR, one 32-bit lane offset - no 64-bit
+// address arithmetic and no address registers inside the bursts
+__device__ inline bf16x8 buffer_frag(__amdgpu_buffer_rsrc_t rs, unsigned lane16, unsigned byte_off) {
+  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, byte_off, 0));
+}
+__device__ inline __amdgpu_buffer_rsrc_t weight_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+
+// Workgroup = 8 waves = 128 tokens, WEIGHT-STATIONARY (round 4).  Every weight byte of a 128-hidden-unit super-chunk is
+// needed by exactly one wave and goes global -> registers; nothing is staged through LDS (the round-3 kernel kept X1 in
+// the producers' registers and walked both weight matrices through LDS: its ds_write_b128 staging was 16.6 % of the step).
 //
-// The two waves of a SIMD share its matrix pipe and its vector issue port, and an in-order wave
-// cannot slip an MFMA into the gaps of its partner's MFMA stream: with both waves mixing MFMAs
-// and VALU work all the time this kernel measured 64 cycles per MFMA (ablations: removing the
-// producers' MFMAs changed nothing, removing the consumers' halved the time).  So every
-// iteration has two phases, separated by workgroup barriers, in which exactly one wave of each
-// SIMD runs a dense MFMA burst while its partner does the vector and memory work:
+//   producer p (waves 0-3)  owns hidden tile p of the super-chunk: its W1 tile [32 x 384] is 24 A fragments in registers
+//                           (each reloaded for the next super-chunk right after its last use); the B operands are the
+//                           X1 fragments of ALL FOUR token tiles, read from a resident 96-KiB LDS image.
+//   consumer q (waves 4-7)  owns output features 96 q .. 96 q + 95 of all 128 tokens (192 accumulators): its W2 slice
+//                           streams through a 9-fragment register window, the h fragments come from LDS (one read per
+//                           three MFMAs).
 //
-//   phase 1   producer: 24 MFMAs  hT = W1[chunk i] X1^T   (weight loads for later chunks in flight)
-//             consumer: GELU of its half of chunk i-1 -> B fragments in registers; first W2
-//                       fragments of its burst
-//   phase 2   consumer: 24 MFMAs  Y^T[12 tiles] += W2[:, chunk i-1] hT[i-1]
-//             producer: bias + GELU of its half of chunk i -> LDS; weight loads -> LDS; first W1
-//                       fragments of chunk i+1
+// The two waves of a SIMD share its matrix pipe and its vector issue port, and an in-order wave cannot slip an MFMA
+// into the gaps of its partner's MFMA stream (both waves mixing MFMAs and VALU work: 64 cycles per MFMA, round 2).  So
+// every super-chunk has two phases, separated by workgroup barriers, in which exactly one wave of each SIMD runs a dense
+// burst of 96 MFMAs while its partner does the vector work:
 //
-// GELU is ~14 VALU instructions per element; it is split between the two waves so that both
-// vector phases are short.  The consumer's half crosses the LDS as fp32 (bias already added), so
-// no value is rounded twice.  The hidden activations never touch HBM.  At the end the consumer holds every
-// feature of its tokens: bias + residual + LayerNorm stay inside the lane pair.
+//   phase 1   producer: hT[sc] = W1[tile] X1^T, 96 MFMAs (first k-step on the constant 0: no accumulator set-up)
+//             consumer: GELU of ITS quarter of the raw half of super-chunk sc - 1 -> h fragments in LDS
+//   phase 2   consumer: Y^T += W2[:, sc - 1] hT[sc - 1], 96 MFMAs
+//             producer: bias + GELU of half its accumulators -> registers; the other half + bias -> LDS as fp32
+//                       (no value is rounded twice); next bias, first X1 fragments of the next burst
 //
-// Hand-over layout.  h^T accumulator element 4g + e of producer lane (r, hp) is hidden unit
-// 8g + 4hp + e of token r = element j = 4hp + e of the B-operand fragment s2 = g >> 1 of consumer
-// lane r + 32 (g & 1).  The producer finishes e = 0, 1 (dword hp of `hdone`, bf16 pair j = 4hp,
-// 4hp + 1) and passes e = 2, 3 on (floats 2hp, 2hp + 1 of `hraw`, j = 4hp + 2, 4hp + 3): the
-// consumer's fragment is { done.x, pk(raw0, raw1), done.y, pk(raw2, raw3) } - whole dwords only.
+// Hand-over.  Accumulator element 4g + e of producer lane (r, hp) is hidden unit 8g + 4hp + e of token r.  W2's image
+// is permuted on the host so that slot j of the consumer's k-step s2 IS that element with g = 2 s2 + (j >> 2),
+// e = j & 3: a producer lane's elements 0..7 / 8..15 are, packed to bf16, exactly ITS OWN lane of the B fragments
+// s2 = 0 / 1 - no cross-lane traffic.  The producer finishes s2 = 0 itself and keeps it in registers until the start
+// of the next phase 1 (the consumers' burst that reads the buffer has ended by then: single buffer), the s2 = 1
+// half crosses as fp32 and consumer q finishes hidden tile q of it.  LDS: X1 image 96 KiB + h fragments 32 KiB + raw half
+// 32 KiB = all 160 KiB; biases and LayerNorm parameters come from global memory (L2).
 //
-// FUSE_OUTPROJ: the attention output projection + residual + LayerNorm (X1) of the workgroup's 128
-// tokens runs as a PROLOGUE here (gemm_n384_ln_block over the weight buffers, which are idle until
-// the chunk loop starts) and hands X1 over as a fragment-order image in LDS: the producers take their
-// B fragments from it, keep them in registers as before and write them back after the last chunk for
-// the consumers' residual.  X1 never reaches HBM (- 300 MB of traffic per layer at 512 x 256) and
-// the separate, load/store-bound projection kernel disappears.
+// Latencies hidden across the barriers: the producers issue the first XR - 1 image reads of a burst BEFORE the barrier
+// that opens it (the image never changes), the consumers start their burst with the fragments they wrote themselves
+// (group order rotated by wave) and read those before the barrier too.
+//
+// FUSE_OUTPROJ: the attention output projection + residual + LayerNorm (X1) of the workgroup's 128 tokens runs as a
+// PROLOGUE (gemm_n384_ln_block; its 96-KiB weight staging area is the image's place, its scratch the raw buffer) and
+// leaves X1 as the fragment-order image: X1 never reaches HBM.
 template <bool FUSE_OUTPROJ>
 __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
-  __shared__ bf16x8 wbuf[4][WTILE_VEC];           // W1: [0..1], W2: [2..3] (chunk i in i % 2), 4 x 24 KiB
-  bf16x8 (*const w1buf)[WTILE_VEC] = wbuf;
-  bf16x8 (*const w2buf)[WTILE_VEC] = wbuf + 2;
-  __shared__ u32x2 hdone[4][2][64];               // [token tile][fragment][consumer lane]
-  __shared__ f32x4 hraw[4][2][64];
-  __shared__ __attribute__((aligned(16))) float b1_lds[FF];
-  __shared__ __attribute__((aligned(16))) float par_lds[3][H];  // b2, gamma, beta
+  __shared__ bf16x8 ximg[4][KSTEPS][64];          // X1 of the workgroup's 128 tokens, fragment order: 96 KiB
+  __shared__ bf16x8 hh[2][4][4][64];              // h fragments [k-step s2][hidden tile][token tile][lane]: 32 KiB
+  __shared__ f32x4 hraw[4][4][2][64];             // the consumers' half of the GELU work, fp32 (bias added): 32 KiB
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool producer = wave < 4;  // wave-uniform
-  const int tg = wave & 3;
+  const int pq = wave & 3;
   const int r = lane & 31, h = lane >> 5;
-  const int tt = blockIdx.x * 4 + tg;
+  const int64_t tile0 = (int64_t)blockIdx.x * 4;
+  const unsigned lane16 = (unsigned)lane * 16u;
 
-  for (int i = tid; i < FF; i += 512) b1_lds[i] = p.b1[i];
-  for (int i = tid; i < H; i += 512) {
-    par_lds[0][i] = p.b2[i];
-    par_lds[1][i] = p.gamma[i];
-    par_lds[2][i] = p.beta[i];
-  }
-  bf16x8* const x1img = &wbuf[0][0];  // FUSE_OUTPROJ: [4 token tiles][24 k-steps][64 lanes] = 96 KiB
+#ifdef SSKD_PROBE   // [60] = {start, image complete, loop entered, loop left}, [61][0] = end
+  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
   if constexpr (FUSE_OUTPROJ) {
-    static_assert(GEMM384_WL_VEC == 4 * WTILE_VEC, "the projection's weight staging area is the MLP's");
+    static_assert(GEMM384_WL_VEC == 4 * KSTEPS * 64, "the projection's weight staging area is the image's place");
     static_assert(sizeof(hraw) >= 128 * 2 * sizeof(float2) + 3 * H * sizeof(float), "prologue scratch");
-    float2* const stats = reinterpret_cast<float2*>(&hraw[0][0][0]);
+    float2* const stats = reinterpret_cast<float2*>(&hraw[0][0][0][0]);
     float* const par = reinterpret_cast<float*>(stats + 128 * 2);
-    gemm_n384_ln_block<2, true>(p.outp, (int64_t)blockIdx.x * 4, 4, x1img, stats, par, x1img);
-    __syncthreads();  // the X1 image is complete
-  }
-  // From here on the two roles never share code: the producers' 96 registers of X1 fragments and the
-  // consumers' 192 accumulators must not be live in one block (the allocator would spill ~90
-  // registers per lane to scratch - 200 MB of extra HBM traffic per layer, measured).  Both branches
-  // execute the same number of workgroup barriers.
-  auto stage_w1_chunk0 = [&]() {
-    if constexpr (FUSE_OUTPROJ) __syncthreads();  // everybody has read the X1 image: the buffers are free
-    for (int i = tid; i < WTILE_VEC; i += 512) w1buf[0][i] = p.w1[i];
-    __syncthreads();
-  };
-  // iterations 0 .. MLP_CHUNKS: the producer's burst is real for it < MLP_CHUNKS, the consumer's
-  // for it >= 1; edge phases work on stale data whose results nobody reads (branch-free).
-  if (producer) {
-    bf16x8 x[KSTEPS];  // the B fragments of this wave's token tile
-    {
-      const bf16x8* xs = FUSE_OUTPROJ ? x1img + frag_base(tg, 0, KSTEPS) + lane : p.x1 + frag_base(tt, 0, KSTEPS) + lane;
-#pragma unroll
-      for (int s = 0; s < KSTEPS; ++s) x[s] = xs[s * 64];
-    }
-    stage_w1_chunk0();
-    // ring of PF + 1 registers: the read issued in slot s targets the register consumed in slot
-    // s - 1, never the one the MFMA just issued is still reading (WAR stall)
-    constexpr int PF = SSKD_MLP_PF, RING = PF + 1;
-    bf16x8 a[RING];
-#pragma unroll
-    for (int i = 0; i < PF; ++i) a[i] = w1buf[0][lane + i * 64];
-    // Weight staging (all of it on the producers: the consumers have no registers to spare) goes
-    // through registers, one vector per thread at a time (a burst of loads would keep all four
-    // producers stuck in the CU's 64 B/clk address path): st1 holds W1 chunk it+1 and st2 W2 chunk
-    // it, loaded one iteration ago; each is written to LDS and immediately reloaded with the
-    // next chunk, one vector after every second MFMA of the burst.  (Moving the W2 half into the
-    // vector phase just moves its ~500 cycles there: measured slower.  Packed-fp32 GELU measured
-    // slower too: v_pk_* is no bargain on these in-order waves.)  W1 chunk it+1 -> buffer (it+1) & 1 (tenant
-    // it-1, last read in the burst of it-1; first read in this iteration's phase 2); W2 chunk it
-    // -> buffer it & 1 (tenant it-2, read by the consumers' burst of it-1; first read in it+1).
-#ifdef SSKD_MLP_DMA
-    // EXPERIMENT: weights by LDS-DMA, 6 pieces per wave and chunk, issued at the START of each role's vector phase:
-    // the producers move W1 chunk it + 2 into the buffer their burst has just left (1.5 iterations of flight time),
-    // the consumers W2 chunk it into the buffer their previous burst left
-    auto dma_w1 = [&](int chunk, int buf) {
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-        glds16(p.w1 + (int64_t)chunk * WTILE_VEC + (wave + 4 * i) * 64 + lane, w1buf[buf] + (wave + 4 * i) * 64);
-    };
-    dma_w1(1, 1);
-#else
-    bf16x8 st1[6], st2[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      st1[i] = p.w1[WTILE_VEC + tid + 256 * i];
-      st2[i] = p.w2c[tid + 256 * i];
-    }
-#endif
-    for (int it = 0; it <= MLP_CHUNKS; ++it) {
-      SSKD_STAMP(0, it, 0);
-      // ---- phase 1: MFMA burst ----
-      f32x16 acc = zero16();
-      {
-        const bf16x8* wl = w1buf[it & 1] + lane;
-        bf16x8* const d1 = w1buf[(it + 1) & 1] + tid;
-        bf16x8* const d2 = w2buf[it & 1] + tid;
-        const bf16x8* const s1 = p.w1 + (int64_t)(it + 2 < MLP_CHUNKS ? it + 2 : MLP_CHUNKS - 1) * WTILE_VEC + tid;
-        const bf16x8* const s2 = p.w2c + (int64_t)(it + 1 < MLP_CHUNKS ? it + 1 : MLP_CHUNKS - 1) * WTILE_VEC + tid;
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(3);  // the burst wins issue arbitration; the partner's VALU fills the gaps
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s % RING], x[s], acc, 0, 0, 0);
-          if (s + PF < KSTEPS) a[(s + PF) % RING] = wl[(s + PF) * 64];
-          // Round-4 measurements of this staging traffic (same-box A/B, whole 12-layer step 6.76 / 6.84 / 6.90 ms on the
-          // three boxes used): without the 12 global loads 6.45 ms (-4.6 %), without loads AND LDS stores 5.64 ms (-16.6 % =
-          // 93 us per layer: the 48 KiB per chunk through ds_write_b128 are the kernel's largest overhead); the same bytes by
-          // LDS-DMA, six pieces per wave and chunk issued at the start of each role's vector phase with counted vmcnt
-          // (-DSSKD_MLP_DMA, bit-identical results): 7.36 vs 6.90 ms (+6.8 %: a DMA piece costs its wave more issue time
-          // than {load, ds_write_b128}); the W2 half moved to the producers' vector phase (-DSSKD_MLP_W2_IN_P2): +2.9 %;
-          // the bias as the first MFMA's C operand: +0.7 %; a 5-VALU GELU (pre-scaled weights): -0.4 %; every 1-KiB store as four
-          // ds_write_addtid_b32 (2 cycles each, no address register; -DSSKD_MLP_ADDTID, timing build): 7.59 vs 6.94 ms (+9 %:
-          // four LDS instructions + the M0 set-up cost the in-order wave more than one ds_write_b128).
-#if !defined(SSKD_MLP_ABL_NOSTAGE) && !defined(SSKD_MLP_DMA)   // timing ablations (tools/ab_build.py): results wrong
-          if (s % 4 == 1) {
-#ifdef SSKD_MLP_ADDTID
-            lds_store_addtid4(lds_offset_of(d1 - lane + 256 * (s / 4)), st1[s / 4]);
-#else
-            d1[256 * (s / 4)] = st1[s / 4];
-#endif
-#ifndef SSKD_MLP_ABL_NOSTAGE_LOADS
-            st1[s / 4] = s1[256 * (s / 4)];
-#endif
-          }
-#ifndef SSKD_MLP_W2_IN_P2
-          if (s % 4 == 3) {
-#ifdef SSKD_MLP_ADDTID
-            lds_store_addtid4(lds_offset_of(d2 - lane + 256 * (s / 4)), st2[s / 4]);
-#else
-            d2[256 * (s / 4)] = st2[s / 4];
-#endif
-#ifndef SSKD_MLP_ABL_NOSTAGE_LOADS
-            st2[s / 4] = s2[256 * (s / 4)];
-#endif
-          }
-#endif
-#endif
-          __builtin_amdgcn_sched_barrier(0);  // keep the reads PF slots ahead of their use
-        }
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      SSKD_STAMP(0, it, 1);
-      __syncthreads();
-      SSKD_STAMP(0, it, 2);
-#ifdef SSKD_MLP_DMA
-      if (it + 2 < MLP_CHUNKS) dma_w1(it + 2, it & 1);
-#endif
-      // ---- phase 2: vector work while the consumer multiplies ----
-      {
-        const int c = it < MLP_CHUNKS ? it : MLP_CHUNKS - 1;
-        f32x4 bias[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          bias[g] = *reinterpret_cast<const f32x4*>(&b1_lds[c * 32 + 8 * g + 4 * h]);
-        // first fragments of the next burst (chunk it+1 was written during this iteration's burst)
-        const bf16x8* wn = w1buf[(it + 1) & 1] + lane;
-#pragma unroll
-        for (int i = 0; i < PF; ++i) a[i] = wn[i * 64];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int dl = r + 32 * (g & 1);
-          f32x2 rw;
-          rw[0] = acc[4 * g + 2] + bias[g][2];
-          rw[1] = acc[4 * g + 3] + bias[g][3];
-          reinterpret_cast<f32x2*>(&hraw[tg][g >> 1][dl])[h] = rw;
-          f32x2 pre;
-          pre[0] = acc[4 * g + 0] + bias[g][0];
-          pre[1] = acc[4 * g + 1] + bias[g][1];
-          bf16x2 pk;
-          pk[0] = (__bf16)gelu_erf(pre[0]);
-          pk[1] = (__bf16)gelu_erf(pre[1]);
-          reinterpret_cast<bf16x2*>(&hdone[tg][g >> 1][dl])[h] = pk;
-        }
-#ifdef SSKD_MLP_W2_IN_P2
-        {   // EXPERIMENT: the W2 half of the staging in the vector phase (W2 chunk it -> buffer it & 1, read from it + 1 on)
-          bf16x8* const d2 = w2buf[it & 1] + tid;
-          const bf16x8* const s2 = p.w2c + (int64_t)(it + 1 < MLP_CHUNKS ? it + 1 : MLP_CHUNKS - 1) * WTILE_VEC + tid;
-#pragma unroll
-          for (int i = 0; i < 6; ++i) {
-            d2[256 * i] = st2[i];
-            st2[i] = s2[256 * i];
-          }
-        }
-#endif
-      }
-      SSKD_STAMP(0, it, 3);
-#ifdef SSKD_MLP_DMA
-      // W1 chunk it + 1 (requested one iteration ago) has landed; the six pieces of chunk it + 2 may stay in flight
-      if (it + 2 < MLP_CHUNKS) __builtin_amdgcn_s_waitcnt(0x0F76);
-      else __builtin_amdgcn_s_waitcnt(0x0F70);
-#endif
-      __syncthreads();
-    }
+    gemm_n384_ln_block<2, true>(p.outp, tile0, 4, &ximg[0][0][0], stats, par, &ximg[0][0][0]);
   } else {
-    f32x16 y[12];
-    if constexpr (FUSE_OUTPROJ) {
-      // Y starts at X1 + b2: the residual is taken from the image NOW, so X1 needs no second home
-      const __bf16* res = reinterpret_cast<const __bf16*>(x1img + frag_base(tg, 0, KSTEPS));
-#pragma unroll
-      for (int nt = 0; nt < 12; ++nt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(&par_lds[0][nt * 32 + 8 * g + 4 * h]);
-          const bf16x4 rr = *reinterpret_cast<const bf16x4*>(res + ((2 * nt + (g >> 1)) * 64 + r + 32 * (g & 1)) * 8 + 4 * h);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) y[nt][4 * g + e] = b[e] + bf2f(rr[e]);
-        }
-    } else {
-#pragma unroll
-      for (int nt = 0; nt < 12; ++nt) y[nt] = zero16();
-    }
-    stage_w1_chunk0();
-    constexpr int CR = 5;  // fragment ring of the burst, in output tiles (reads run CR - 1 tiles ahead)
-    for (int it = 0; it <= MLP_CHUNKS; ++it) {
-      SSKD_STAMP(1, it, 0);
-#ifdef SSKD_MLP_DMA
-      if (it < MLP_CHUNKS) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-          glds16(p.w2c + (int64_t)it * WTILE_VEC + (tg + 4 * i) * 64 + lane, w2buf[it & 1] + (tg + 4 * i) * 64);
-      }
+    const bf16x8* xs = p.x1 + frag_base(tile0, 0, KSTEPS);
+    bf16x8* xd = &ximg[0][0][0];
+    for (int i = tid; i < 4 * KSTEPS * 64; i += 512) xd[i] = xs[i];
+  }
+  __syncthreads();  // the X1 image is complete
+
+  // From here on the two roles never share code: the producers' 96 registers of W1 fragments and the consumers' 192
+  // accumulators must not be live in one block.  Both branches execute the same number of workgroup barriers
+  // (2 MLP_SUPER + 3).
+  if (producer) {
+    const int hp = pq;
+    SSKD_STAMP(0, 60, 1);
+#ifdef SSKD_PROBE
+    if (blockIdx.x == 0 && pq == 0 && lane == 0) g_probe[0][60][0] = t_begin;
 #endif
-      // ---- phase 1: vector work while the producer multiplies ----
-      bf16x8 hf0, hf1;
-      bf16x8 a[CR][2];
-      const bf16x8* wl = w2buf[(it + 1) & 1] + lane;  // chunk it-1, staged in phase 2 of it-1
+    const __amdgpu_buffer_rsrc_t w1rs = weight_rsrc(p.w1);
+    bf16x8 w[KSTEPS];
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) w[s] = buffer_frag(w1rs, lane16, (unsigned)((hp * KSTEPS + s) * 1024));
+    f32x4 bias[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias[g] = *reinterpret_cast<const f32x4*>(p.b1 + hp * 32 + 8 * g + 4 * h);
+    bf16x8 fd[4];   // this wave's finished half of the previous super-chunk
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) fd[tt] = zero_bf8();
+    const bf16x8* xl = &ximg[0][0][lane];
+    // slot n = 4 s + tt of a burst multiplies fragment (tt, s) of the image
+    constexpr int XR = SSKD_MLP_XR, NS = 4 * KSTEPS;
+    auto xat = [](int n) { return ((n & 3) * KSTEPS + (n >> 2)) * 64; };
+    bf16x8 xb[XR];
+#pragma unroll
+    for (int i = 0; i < XR - 1; ++i) xb[i] = xl[xat(i)];
+    SSKD_STAMP(0, 60, 2);
+    for (int it = 0; it < MLP_SUPER; ++it) {   // the consumers run one iteration behind (their last one is peeled below)
+      f32x16 acc[4];
+      SSKD_STAMP(0, it, 0);
       {
-        u32x4 hn[2];
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-          const u32x2 dn = hdone[tg][f][lane];
-          const f32x4 rw = hraw[tg][f][lane];
-          bf16x2 lo, hi;
-          lo[0] = (__bf16)gelu_erf(rw[0]);
-          lo[1] = (__bf16)gelu_erf(rw[1]);
-          hi[0] = (__bf16)gelu_erf(rw[2]);
-          hi[1] = (__bf16)gelu_erf(rw[3]);
-          hn[f][0] = dn[0];
-          hn[f][1] = __builtin_bit_cast(unsigned int, lo);
-          hn[f][2] = dn[1];
-          hn[f][3] = __builtin_bit_cast(unsigned int, hi);
-        }
-        // (the fragments are only used inside the conditional burst below: without this the
-        // compiler sinks the whole GELU computation past the barrier, into the burst phase)
-        asm volatile("" : "+v"(hn[0]), "+v"(hn[1]));
-        hf0 = __builtin_bit_cast(bf16x8, hn[0]);
-        hf1 = __builtin_bit_cast(bf16x8, hn[1]);
-        // first fragments of the burst
-#pragma unroll
-        for (int i = 0; i < CR - 1; ++i) {
-          a[i][0] = wl[(2 * i) * 64];
-          a[i][1] = wl[(2 * i + 1) * 64];
-        }
-      }
-      SSKD_STAMP(1, it, 1);
-#ifdef SSKD_MLP_DMA
-      // W2 chunk it - 1 (requested one iteration ago) has landed; the six pieces of chunk it may stay in flight
-      if (it < MLP_CHUNKS) __builtin_amdgcn_s_waitcnt(0x0F76);
-      else __builtin_amdgcn_s_waitcnt(0x0F70);
-#endif
-      __syncthreads();
-      SSKD_STAMP(1, it, 2);
-      // ---- phase 2: MFMA burst, 12 output tiles x 2 k-steps ----
-      if (it >= 1) {
+        const unsigned wnext = (unsigned)(((it + 1 < MLP_SUPER ? it + 1 : it) * 4 + hp) * KSTEPS * 1024);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(3);
 #pragma unroll
-        for (int nt = 0; nt < 12; ++nt) {
-          if (nt + CR - 1 < 12) {
-            a[(nt + CR - 1) % CR][0] = wl[((nt + CR - 1) * 2) * 64];
-            a[(nt + CR - 1) % CR][1] = wl[((nt + CR - 1) * 2 + 1) * 64];
+        for (int n = 0; n < NS; ++n) {
+          const int s = n >> 2, tt = n & 3;
+          if (n + XR - 1 < NS) xb[(n + XR - 1) % XR] = xl[xat(n + XR - 1)];
+          acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[s], xb[n % XR], s == 0 ? zero16() : acc[tt], 0, 0, 0);
+          if (n < 4) hh[0][hp][n][lane] = fd[n];   // the finished half of the previous super-chunk, behind the first MFMAs
+          if (tt == 3) w[s] = buffer_frag(w1rs, lane16, wnext + s * 1024);   // last use: fetch the next super-chunk's
+          __builtin_amdgcn_sched_barrier(0);   // one slot = one MFMA: keeps every request where it is written
+        }
+        __builtin_amdgcn_s_setprio(0);
+      }
+      SSKD_STAMP(0, it, 1);
+      __builtin_amdgcn_sched_barrier(0);   // the GELU belongs behind the barrier (the consumers' burst waits on it)
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      SSKD_STAMP(0, it, 2);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fd[tt][i] = (__bf16)gelu_erf(acc[tt][i] + bias[i >> 2][i & 3]);
+        f32x4 r0, r1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          r0[e] = acc[tt][8 + e] + bias[2][e];
+          r1[e] = acc[tt][12 + e] + bias[3][e];
+        }
+        hraw[hp][tt][0][lane] = r0;
+        hraw[hp][tt][1][lane] = r1;
+      }
+      // pin the finished values here, or the compiler sinks their whole computation past the barrier into the burst
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        u32x4 t = __builtin_bit_cast(u32x4, fd[tt]);
+        asm volatile("" : "+v"(t));
+        fd[tt] = __builtin_bit_cast(bf16x8, t);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      {   // the next super-chunk's bias and the ring's first fragments: both a whole phase ahead of their use
+        const int nx = it + 1 < MLP_SUPER ? it + 1 : it;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias[g] = *reinterpret_cast<const f32x4*>(p.b1 + nx * 128 + hp * 32 + 8 * g + 4 * h);
+#pragma unroll
+        for (int i = 0; i < XR - 1; ++i) xb[i] = xl[xat(i)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      SSKD_STAMP(0, it, 3);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) hh[0][hp][tt][lane] = fd[tt];
+    SSKD_STAMP(0, 60, 3);
+    __syncthreads();
+    __syncthreads();
+    __syncthreads();   // the consumers' LayerNorm statistics meet behind this barrier
+    SSKD_STAMP(0, 61, 0);
+  } else {
+    const int fq = pq;
+    SSKD_STAMP(1, 60, 1);
+#ifdef SSKD_PROBE
+    if (blockIdx.x == 0 && pq == 0 && lane == 0) g_probe[1][60][0] = t_begin;
+#endif
+    // y starts as bias + residual (the image is X1): the epilogue is the LayerNorm alone
+    f32x16 y[3][4];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int nt = fq * 3 + j;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const __bf16* res = reinterpret_cast<const __bf16*>(&ximg[tt][0][0]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(p.b2 + nt * 32 + 8 * g + 4 * h);
+          const bf16x4 rr = *reinterpret_cast<const bf16x4*>(res + ((2 * nt + (g >> 1)) * 64 + r + 32 * (g & 1)) * 8 + 4 * h);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[j][tt][4 * g + e] = b[e] + bf2f(rr[e]);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // one tile at a time: hoisted loads would spill the accumulators for good
+      }
+    }
+    // Group order of this wave: position cs -> (hidden tile cc, k-step s2) = (cs + 2 fq + 1) mod 8, i.e. it starts with
+    // the fragments (fq, 1) this wave wrote itself in phase 1.  Fragment f = 3 cs + j of super-chunk sc is
+    // w2p[(((4 sc + cc) * 12 + 3 fq + j) * 2 + s2) * 64 + lane]; 24 fragments per super-chunk walk through 9 registers,
+    // the sequence padded to 27 so that fragment f always lives in register f % 9.
+    const __amdgpu_buffer_rsrc_t w2rs = weight_rsrc(p.w2p);
+    const int rot = 2 * fq + 1;
+    auto frag_ld = [&](int sc, int f) {
+      const int cs = f / 3, j = f - cs * 3, csr = (cs + rot) & 7, cc = csr >> 1, s2 = csr & 1;
+      return buffer_frag(w2rs, lane16, (unsigned)((((4 * sc + cc) * 12 + 3 * fq + j) * 2 + s2) * 1024));
+    };
+    constexpr int NF = 24;
+    bf16x8 a[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a[i] = frag_ld(0, i);
+    __syncthreads();   // iteration 0: nothing to consume yet
+    __syncthreads();
+    for (int it = 1; it <= MLP_SUPER; ++it) {
+      SSKD_STAMP(1, it, 0);
+      // phase 1: GELU of this wave's share (hidden tile fq, k-step 1) of the previous super-chunk's raw half
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {   // four values at a time: 192 accumulators leave ~25 registers for this
+        bf16x8 f;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const f32x4 rw = hraw[fq][tt][hf][lane];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) f[4 * hf + e] = (__bf16)gelu_erf(rw[e]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        hh[1][fq][tt][lane] = f;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // the burst walks (group cs, token tile tt); a group's three W2 fragments stay in registers while the four token
+      // tiles' h fragments stream through a ring of HR (one LDS read per three MFMAs, two reads ahead)
+      constexpr int HR = 3;
+      const bf16x8* hl = &hh[0][0][0][lane];
+      auto hidx = [&](int g) {
+        const int csr = ((g >> 2) + rot) & 7, tt = g & 3;
+        return ((csr & 1) * 16 + (csr >> 1) * 4 + tt) * 64;
+      };
+      bf16x8 hb[HR];
+#pragma unroll
+      for (int i = 0; i < HR - 1; ++i) hb[i] = hl[hidx(i)];   // own fragments (same wave: ordered behind the writes above)
+      __builtin_amdgcn_sched_barrier(0);
+      SSKD_STAMP(1, it, 3);
+      __syncthreads();
+      SSKD_STAMP(1, it, 1);
+      {
+        const int sc = it - 1;
+        const int scn = sc + 1 < MLP_SUPER ? sc + 1 : sc;
+        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 32; ++g) {
+          const int cs = g >> 2, tt = g & 3;
+          if (g + HR - 1 < 32) hb[(g + HR - 1) % HR] = hl[hidx(g + HR - 1)];
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            y[j][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(cs * 3 + j) % 9], hb[g % HR], y[j][tt], 0, 0, 0);
+          if (tt == 3) {   // the group is finished: refill its registers (f + 9 < 24: this super-chunk's fragment f + 9;
+                           // f + 9 >= 27: the next one's fragment f - 18)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              const int f = cs * 3 + j, fn = f + 9;
+              if (fn < NF) a[f % 9] = frag_ld(sc, fn);
+              else if (fn >= 27) a[f % 9] = frag_ld(scn, fn - 27);
+            }
+            if (cs == 7) {   // the pad: fragments 6 .. 8 of the next super-chunk
+#pragma unroll
+              for (int j = 6; j < 9; ++j) a[j] = frag_ld(scn, j);
+            }
           }
-          y[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt % CR][0], hf0, y[nt], 0, 0, 0);
-          y[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt % CR][1], hf1, y[nt], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
       }
-      SSKD_STAMP(1, it, 3);
+      SSKD_STAMP(1, it, 2);
       __syncthreads();
     }
-
-    // epilogue: v = y + b2 + residual; LayerNorm over the token's 384 features (192 in this
-    // lane, 192 in lane ^ 32)
-    float sum = 0.f, sq = 0.f;
-    if constexpr (FUSE_OUTPROJ) {
+    // epilogue: LayerNorm over the token's 384 features - 48 in this lane, 48 in lane ^ 32, 96 per consumer
+    SSKD_STAMP(1, 60, 3);
+    float2* const stats = reinterpret_cast<float2*>(&hraw[0][0][0][0]);   // dead by now: [128 tokens][4 consumers]
 #pragma unroll
-      for (int nt = 0; nt < 12; ++nt)
+    for (int tt = 0; tt < 4; ++tt) {
+      float sum = 0.f, sq = 0.f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          sum += y[nt][i];
-          sq = fmaf(y[nt][i], y[nt][i], sq);
+          sum += y[j][tt][i];
+          sq = fmaf(y[j][tt][i], y[j][tt][i], sq);
         }
-    } else {
-      const __bf16* res = reinterpret_cast<const __bf16*>(p.x1 + frag_base(tt, 0, KSTEPS));
+      sum = pair_sum(sum);
+      sq = pair_sum(sq);
+      if (h == 0) stats[(tt * 32 + r) * 4 + fq] = make_float2(sum, sq);
+    }
+    __syncthreads();
 #pragma unroll
-      for (int nt = 0; nt < 12; ++nt)
+    for (int tt = 0; tt < 4; ++tt) {
+      float sum = 0.f, sq = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float2 t = stats[(tt * 32 + r) * 4 + k];
+        sum += t.x;
+        sq += t.y;
+      }
+      const float mean = sum * (1.0f / H);
+      const float var = fmaxf(sq * (1.0f / H) - mean * mean, 0.f);
+      const float rstd = rsqrtf(var + p.eps);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int nt = fq * 3 + j;
+        f32x4 v[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(&par_lds[0][nt * 32 + 8 * g + 4 * h]);
-          const bf16x4 rr = *reinterpret_cast<const bf16x4*>(
-              res + ((int64_t)((2 * nt + (g >> 1)) * 64 + r + 32 * (g & 1))) * 8 + 4 * h);
+          const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + nt * 32 + 8 * g + 4 * h);
+          const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + nt * 32 + 8 * g + 4 * h);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float v = y[nt][4 * g + e] + b[e] + bf2f(rr[e]);
-            y[nt][4 * g + e] = v;
-            sum += v;
-            sq = fmaf(v, v, sq);
-          }
+          for (int e = 0; e < 4; ++e) v[g][e] = (y[j][tt][4 * g + e] - mean) * rstd * ga[e] + be[e];
         }
-    }
-    sum = pair_sum(sum);
-    sq = pair_sum(sq);
-    const float mean = sum * (1.0f / H);
-    const float var = fmaxf(sq * (1.0f / H) - mean * mean, 0.f);
-    const float rstd = rsqrtf(var + p.eps);
-#pragma unroll
-    for (int nt = 0; nt < 12; ++nt) {
-      f32x4 v[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 ga = *reinterpret_cast<const f32x4*>(&par_lds[1][nt * 32 + 8 * g + 4 * h]);
-        const f32x4 be = *reinterpret_cast<const f32x4*>(&par_lds[2][nt * 32 + 8 * g + 4 * h]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[g][e] = (y[nt][4 * g + e] - mean) * rstd * ga[e] + be[e];
+        store_tile_frag(p.out + frag_base(tile0 + tt, 2 * nt, KSTEPS) * 8, v, lane);
       }
-      store_tile_frag(p.out + frag_base(tt, 2 * nt, KSTEPS) * 8, v, lane);
     }
+    SSKD_STAMP(1, 61, 0);
   }
 }
 
@@ -1498,7 +1422,7 @@ int run_layers(const sskd_encoder_config* cfg, const sskd_encoder_weights* w, co
     m.x1 = nullptr;
     m.w1 = static_cast<const bf16x8*>(lw.w1);
     m.b1 = lw.b1;
-    m.w2c = static_cast<const bf16x8*>(lw.w2);
+    m.w2p = static_cast<const bf16x8*>(lw.w2);
     m.b2 = lw.b2;
     m.gamma = lw.ln2_g;
     m.beta = lw.ln2_b;

@@ -190,12 +190,15 @@ def tile_weight_fragments(w: np.ndarray) -> np.ndarray:
 
 def tile_w2_chunked(w2: np.ndarray) -> np.ndarray:
     """``W2[384, 1536]`` -> ``[48 chunks][12 tiles][2 k-steps][64 lanes][8]`` for the fused MLP: the
-    consumer waves' A operand for hidden chunk ``c`` (features 32c..32c+31), lane ``l`` holding
-    ``W2[32 nt + (l & 31)][32 c + 16 s2 + 8 (l >> 5) + j]`` (csrc/encoder.hip fused_mlp_ln_kernel)."""
+    consumer waves' A operand for hidden chunk ``c`` (features 32c..32c+31).  The k slots are
+    permuted so that the producers' accumulators ARE the matching B fragments, lane for lane:
+    lane ``l``, slot ``j`` of fragment ``(c, nt, s2)`` holds
+    ``W2[32 nt + (l & 31)][32 c + 16 s2 + 8 (j >> 2) + 4 (l >> 5) + (j & 3)]``
+    (csrc/encoder.hip fused_mlp_ln_kernel, "Hand-over")."""
     n, k = w2.shape
     assert n % 32 == 0 and k % 32 == 0, (n, k)
-    t = w2.reshape(n // 32, 32, k // 32, 2, 2, 8)   # [nt, r, c, s2, h, j]
-    t = t.transpose(2, 0, 3, 4, 1, 5)               # [c, nt, s2, h, r, j] -> lane = 32 h + r
+    t = w2.reshape(n // 32, 32, k // 32, 2, 2, 2, 4)   # [nt, r, c, s2, jh, h, jl]: unit = 16 s2 + 8 jh + 4 h + jl
+    t = t.transpose(2, 0, 3, 5, 1, 4, 6)               # [c, nt, s2, h, r, jh, jl] -> lane = 32 h + r, j = 4 jh + jl
     return np.ascontiguousarray(t.reshape(k // 32, n // 32, 2, 64, 8))
 
 

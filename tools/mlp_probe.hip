@@ -1,48 +1,146 @@
-// Diagnostic only: runs fused_mlp_ln_kernel on random data with s_memtime stamps (SSKD_PROBE)
-// and prints where producer / consumer waves of workgroup 0 spend an iteration.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DSSKD_PROBE -Iinclude -Isemantic-search-kd_amd/csrc \
-//         tools/mlp_probe.hip semantic-search-kd_amd/csrc/capi_common.hip semantic-search-kd_amd/csrc/pool.hip -o /tmp/mlp_probe
+// Diagnostic only: runs fused_mlp_ln_kernel<false> (the chunk loop alone, X1 from HBM) on random data, checks 64 tokens
+// against a host fp32 restatement and prints the launch time; with -DSSKD_PROBE also the s_memtime stamps of workgroup 0
+// (producer wave 0, consumer wave 4): where the two roles spend a super-chunk.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize [-DSSKD_PROBE] -Iinclude -Isemantic-search-kd_amd/csrc \
+//         tools/mlp_probe.hip semantic-search-kd_amd/csrc/capi_common.hip semantic-search-kd_amd/csrc/pool.hip -o tools/mlp_probe.bin
 #include "../semantic-search-kd_amd/csrc/encoder.hip"
 
+#include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
+
+static unsigned short f2bf(float f) {
+  unsigned u;
+  std::memcpy(&u, &f, 4);
+  return (unsigned short)((u + 0x7FFF + ((u >> 16) & 1)) >> 16);
+}
+static float bf2float(unsigned short b) {
+  unsigned u = (unsigned)b << 16;
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+static float rbf(float f) { return bf2float(f2bf(f)); }
 
 int main() {
   const int T = 131072;
-  std::vector<unsigned short> h(1 << 20);
-  for (size_t i = 0; i < h.size(); ++i) h[i] = 0x3c00 + (unsigned short)((i * 2654435761u) >> 22);  // ~[0.008, 0.03]
-  auto dalloc = [&](size_t bytes) {
-    void* p = nullptr;
-    hipMalloc(&p, bytes);
-    for (size_t off = 0; off < bytes; off += h.size() * 2)
-      hipMemcpy((char*)p + off, h.data(), std::min(h.size() * 2, bytes - off), hipMemcpyHostToDevice);
-    return p;
+  srand(7);
+  auto rnd = [](float s) { return s * ((rand() & 0xffff) / 32768.0f - 1.0f); };
+  std::vector<float> W1((size_t)FF * H), W2((size_t)H * FF);
+  for (auto& v : W1) v = rbf(rnd(0.06f));
+  for (auto& v : W2) v = rbf(rnd(0.04f));
+  // device images: W1 as A fragments per 32-unit tile, W2 chunk-major with the permuted k slots (weights.tile_w2_chunked)
+  std::vector<unsigned short> w1img((size_t)FF * H), w2p((size_t)FF * H);
+  for (int c = 0; c < 48; ++c)
+    for (int s = 0; s < 24; ++s)
+      for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 8; ++j)
+          w1img[(((size_t)c * 24 + s) * 64 + l) * 8 + j] = f2bf(W1[(size_t)(32 * c + (l & 31)) * H + 16 * s + 8 * (l >> 5) + j]);
+  for (int c = 0; c < 48; ++c)
+    for (int nt = 0; nt < 12; ++nt)
+      for (int s2 = 0; s2 < 2; ++s2)
+        for (int l = 0; l < 64; ++l)
+          for (int j = 0; j < 8; ++j)
+            w2p[((((size_t)c * 12 + nt) * 2 + s2) * 64 + l) * 8 + j] =
+                f2bf(W2[(size_t)(32 * nt + (l & 31)) * FF + 32 * c + 16 * s2 + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3)]);
+  // X1 in fragment order: element j of lane l of fragment (tile, s) = token 32 tile + (l & 31), feature 16 s + 8 (l >> 5) + j
+  std::vector<unsigned short> xh((size_t)T * H);
+  for (auto& v : xh) v = f2bf(rnd(1.5f));
+  std::vector<float> fl(8192);
+  for (auto& v : fl) v = rnd(0.3f);
+  for (int i = 3072; i < 3072 + 384; ++i) fl[i] = 1.0f + fl[i];   // gamma around 1
+  auto up = [&](const void* src, size_t bytes) {
+    void* d = nullptr;
+    (void)hipMalloc(&d, bytes);
+    (void)hipMemcpy(d, src, bytes, hipMemcpyHostToDevice);
+    return d;
   };
   MlpParams m{};
-  m.x1 = (const bf16x8*)dalloc((size_t)T * 384 * 2);
-  m.w1 = (const bf16x8*)dalloc(1536 * 384 * 2);
-  m.w2c = (const bf16x8*)dalloc(1536 * 384 * 2);
-  float* f = (float*)dalloc(8192 * 4);
-  hipMemset(f, 0, 8192 * 4);
+  m.x1 = (const bf16x8*)up(xh.data(), xh.size() * 2);
+  m.w1 = (const bf16x8*)up(w1img.data(), w1img.size() * 2);
+  m.w2p = (const bf16x8*)up(w2p.data(), w2p.size() * 2);
+  float* f = (float*)up(fl.data(), fl.size() * 4);
   m.b1 = f; m.b2 = f + 2048; m.gamma = f + 3072; m.beta = f + 4096;
   m.eps = 1e-12f;
-  m.out = (__bf16*)dalloc((size_t)T * 384 * 2);
-  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int rep = 0; rep < 3; ++rep) {
-    hipEventRecord(e0);
+  void* out = nullptr;
+  (void)hipMalloc(&out, (size_t)T * H * 2);
+  m.out = (__bf16*)out;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  for (int rep = 0; rep < 6; ++rep) {
+    (void)hipEventRecord(e0);
     hipLaunchKernelGGL(fused_mlp_ln_kernel<false>, dim3(T / 128), dim3(512), 0, 0, m);
-    hipEventRecord(e1); hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms;
+    (void)hipEventElapsedTime(&ms, e0, e1);
     printf("launch %d: %.1f us (%s)\n", rep, ms * 1e3, hipGetErrorString(hipGetLastError()));
   }
-  unsigned long long pr[2][64][4];
-  hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_probe), sizeof(pr));
-  printf("it   | producer: stage  compute  barrier | consumer: stage  compute  barrier | iter(P)\n");
-  for (int it = 8; it < 20; ++it) {
-    printf("%3d  | %8llu %8llu %8llu | %8llu %8llu %8llu | %8llu\n", it,
-           pr[0][it][1] - pr[0][it][0], pr[0][it][2] - pr[0][it][1], pr[0][it][3] - pr[0][it][2],
-           pr[1][it][1] - pr[1][it][0], pr[1][it][2] - pr[1][it][1], pr[1][it][3] - pr[1][it][2],
-           pr[0][it + 1][0] - pr[0][it][0]);
+  std::vector<unsigned short> o((size_t)T * H);
+  (void)hipMemcpy(o.data(), out, o.size() * 2, hipMemcpyDeviceToHost);
+  auto at = [&](const std::vector<unsigned short>& v, int tok, int feat) {
+    const int tile = tok >> 5, rr = tok & 31, s = feat >> 4, hh = (feat >> 3) & 1, j = feat & 7;
+    return bf2float(v[(((size_t)tile * 24 + s) * 64 + 32 * hh + rr) * 8 + j]);
+  };
+  double maxd = 0;
+  for (int k = 0; k < 64; ++k) {
+    const int tok = (int)(((unsigned)k * 2654435761u) % (unsigned)T);
+    std::vector<float> x(H), hid(FF), y(H);
+    for (int i = 0; i < H; ++i) x[i] = at(xh, tok, i);
+    for (int u = 0; u < FF; ++u) {
+      float a = 0.f;
+      for (int i = 0; i < H; ++i) a += W1[(size_t)u * H + i] * x[i];
+      a += fl[u];
+      hid[u] = rbf(0.5f * a * (1.0f + std::erf(a * 0.70710678f)));
+    }
+    double sum = 0, sq = 0;
+    for (int n = 0; n < H; ++n) {
+      float a = 0.f;
+      for (int u = 0; u < FF; ++u) a += W2[(size_t)n * FF + u] * hid[u];
+      y[n] = a + fl[2048 + n] + x[n];
+      sum += y[n];
+      sq += (double)y[n] * y[n];
+    }
+    const double mean = sum / H, var = sq / H - mean * mean, rstd = 1.0 / std::sqrt(var + 1e-12);
+    for (int n = 0; n < H; ++n) {
+      const double want = (y[n] - mean) * rstd * fl[3072 + n] + fl[4096 + n];
+      maxd = std::fmax(maxd, std::fabs(want - at(o, tok, n)));
+    }
   }
-  return 0;
+  printf("64 tokens against the host restatement: max |diff| %.4f (bf16 output, values of order 1: <= 0.03 expected)\n", maxd);
+  // the layer's real kernel: the attention output projection + LayerNorm as the prologue (random ctx / Wo; timing only)
+  {
+    std::vector<unsigned short> wo((size_t)H * H), ctx((size_t)T * H);
+    for (auto& v : wo) v = f2bf(rnd(0.05f));
+    for (auto& v : ctx) v = f2bf(rnd(1.0f));
+    m.outp.x = (const bf16x8*)up(ctx.data(), ctx.size() * 2);
+    m.outp.w = (const bf16x8*)up(wo.data(), wo.size() * 2);
+    m.outp.bias = f + 5120; m.outp.gamma = f + 3072; m.outp.beta = f + 4096;
+    m.outp.resid = (const __bf16*)m.x1;
+    m.outp.eps = 1e-12f;
+    for (int rep = 0; rep < 4; ++rep) {
+      (void)hipEventRecord(e0);
+      hipLaunchKernelGGL(fused_mlp_ln_kernel<true>, dim3(T / 128), dim3(512), 0, 0, m);
+      (void)hipEventRecord(e1);
+      (void)hipEventSynchronize(e1);
+      float ms;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      printf("with the projection prologue, launch %d: %.1f us (%s)\n", rep, ms * 1e3, hipGetErrorString(hipGetLastError()));
+    }
+  }
+#ifdef SSKD_PROBE
+  unsigned long long pr[2][64][4];
+  (void)hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_probe), sizeof(pr));
+  printf("it | producer: burst  wait  gelu | consumer: gelu  burst | iteration\n");
+  for (int it = 3; it < 9; ++it)
+    printf("%2d | %6llu %6llu %6llu | %6llu %6llu | %6llu\n", it, pr[0][it][1] - pr[0][it][0], pr[0][it][2] - pr[0][it][1],
+           pr[0][it][3] - pr[0][it][2], pr[1][it][3] - pr[1][it][0], pr[1][it][2] - pr[1][it][1], pr[0][it + 1][0] - pr[0][it][0]);
+  printf("whole kernel (with prologue), cycles: producer  image %llu  set-up %llu  loop %llu  tail %llu | consumer  image %llu  set-up %llu  loop %llu  epilogue %llu\n",
+         pr[0][60][1] - pr[0][60][0], pr[0][60][2] - pr[0][60][1], pr[0][60][3] - pr[0][60][2], pr[0][61][0] - pr[0][60][3],
+         pr[1][60][1] - pr[1][60][0], pr[1][1][0] - pr[1][60][1], pr[1][60][3] - pr[1][1][0], pr[1][61][0] - pr[1][60][3]);
+#endif
+  return maxd <= 0.03 ? 0 : 1;
 }
