@@ -213,213 +213,165 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(
 // shared pieces of the GEMM kernels
 // ------------------------------------------------------------------------- //
 
-// NS MFMAs of one weight tile held in LDS as lane-linear fragments (wl already points at this
-// lane's 16 bytes of fragment 0), against register-resident activations.  LDS reads are
-// issued one whole group of GS fragments ahead of their use so that their latency hides
-// under the previous group's MFMAs instead of stalling every second MFMA.
-template <int NS, int GS, int VALU_PER_MFMA = 0>
-__device__ inline f32x16 tile_mfma(const bf16x8* __restrict__ wl, const bf16x8 (&x)[NS], f32x16 acc) {
-  static_assert(NS % GS == 0, "group size must divide the k-steps");
-  constexpr int NG = NS / GS;
-  bf16x8 a[2][GS];
-#pragma unroll
-  for (int i = 0; i < GS; ++i) a[0][i] = wl[i * 64];
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    if (g + 1 < NG) {
-#pragma unroll
-      for (int i = 0; i < GS; ++i) a[(g + 1) & 1][i] = wl[((g + 1) * GS + i) * 64];
-    }
-#pragma unroll
-    for (int i = 0; i < GS; ++i)
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g & 1][i], x[g * GS + i], acc, 0, 0, 0);
-  }
-  // pin the pipeline in the machine scheduler (it otherwise sinks every read to just before
-  // its MFMA): reads(g0), then { reads(g+1), MFMAs(g) } ...   masks: 0x100 = DS read, 0x8 = MFMA,
-  // 0x2 = VALU.  With VALU_PER_MFMA > 0 every MFMA is followed by a slice of the caller's
-  // independent VALU work (the previous tile's epilogue), so that an in-order wave keeps the
-  // matrix pipe fed while it works through its epilogue.
-  __builtin_amdgcn_sched_group_barrier(0x100, GS, 0);
-  if (VALU_PER_MFMA == 0) {
-#pragma unroll
-    for (int g = 0; g + 1 < NG; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x100, GS, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, GS, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, GS, 0);
-  } else {
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (i < NS - GS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);
-    }
-  }
-  return acc;
-}
-
 struct GemmN384Params {
-  const bf16x8* x;        // fragment-order [T_pad, 192 * KC2]
-  const bf16x8* w;        // tiled [12][12 * KC2][64] fragments
+  const bf16x8* x;        // fragment-order [T_pad, 384]: the attention context
+  const bf16x8* w;        // tiled [12][24][64] fragments of Wo [384, 384]
   const float* bias;      // [384]
   const __bf16* resid;    // fragment-order [T_pad, 384]
   const float* gamma;
   const float* beta;
   float eps;
-  __bf16* out;            // fragment-order [T_pad, 384]
 };
 
-constexpr int KS2 = 12;                  // k-steps of one 192-wide K chunk
-constexpr int HTILE_VEC = 32 * 192 / 8;  // bf16x8 vectors of one [32 x 192] weight half-tile (12 KiB)
+// LDS-DMA: 16 B per lane, global -> LDS, no registers (LDS address = wave-uniform base + 16 lane)
+__device__ inline void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
 
-// N = 384 GEMM (K = 192 * KC2) with fused bias + residual + LayerNorm epilogue, for the 4 token
-// tiles tt0 .. tt0 + 3 of a 512-thread workgroup.
-// 8 waves = 4 token tiles x 2 feature halves: wave = (token tile tg, feature half nh); each wave
-// accumulates its 6 output tiles (192 features of its tokens) in 96 registers, the LayerNorm
-// statistics of the two halves meet through 2 KiB of LDS.  K is walked in 192-wide chunks so
-// that activations (48 VGPRs) + accumulators + fragment prefetch fit 2 waves/SIMD.
-// LDS (caller-provided): wl = 2 buffers x [feature half][2 tiles][768 vectors] = 96 KiB,
-// stats = [128] float2 pairs x 2, par = [3][384] floats (bias, gamma, beta; filled here).
-// `n_valid` = how many of the 4 token tiles exist (the others compute on tile tt0 and store
-// nothing).  Every wave of the workgroup must call this (it contains workgroup barriers).
-constexpr int GEMM384_WL_VEC = 2 * 2 * 2 * HTILE_VEC;  // bf16x8 vectors of the weight staging area
+// 16 B per lane through a buffer resource: wave-uniform fragment offset in an SGPR, one 32-bit lane offset - no 64-bit
+// address arithmetic and no address registers inside the MFMA bursts
+__device__ inline bf16x8 buffer_frag(__amdgpu_buffer_rsrc_t rs, unsigned lane16, unsigned byte_off) {
+  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, byte_off, 0));
+}
+__device__ inline __amdgpu_buffer_rsrc_t weight_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
 
-// OUT_LDS: the normalised rows are written as a fragment-order image of the 4 token tiles into `img`
-// (which may alias `wl`: the weight buffers are dead by then) instead of p.out.
-template <int KC2, bool OUT_LDS = false>
-__device__ inline void gemm_n384_ln_block(const GemmN384Params& p, int64_t tt0, int n_valid,
-                                          bf16x8* __restrict__ wl, float2* __restrict__ stats,
-                                          float* __restrict__ par, bf16x8* img = nullptr) {
+// Prologue of the fused MLP: X1 = LN(resid + ctx Wo^T + bo) for the 4 token tiles tt0 .. tt0 + 3 of a 512-thread
+// workgroup, left as the fragment-order image `img` (96 KiB of LDS).  Weight-stationary like the MLP itself (round 4):
+//   - the context rows arrive as a fragment-order image by LDS-DMA (96 pieces of 1 KiB, no registers), the residual rows
+//     and the first Wo fragments are requested in the same breath: ONE memory round trip before the first MFMA (the round-2/3
+//     block staged Wo through LDS in six barrier-separated steps and waited a load latency in each: 31-41 k cycles
+//     for 9 k cycles of MFMAs, tools/mlp_probe.hip);
+//   - wave = (feature group fg: output tiles 3 fg .. 3 fg + 2, token half th: tiles 2 th, 2 th + 1), 6 accumulators; its
+//     Wo fragments stream global -> registers through a 12-deep window (each used for both token tiles), the context
+//     fragments come from the image (each read feeds 3 MFMAs);
+//   - bias + residual + LayerNorm: a token's 384 features live in 4 waves x 2 lanes; the partial sums meet through
+//     `stats` ([128 tokens][4 groups], 4 KiB), behind the barrier that also ends everybody's reads of the context image;
+//     the normalised rows then overwrite it.
+// Every wave of the workgroup must call this (two workgroup barriers inside); the caller adds the one that completes
+// the image.
+__device__ inline void outproj_ln_image(const GemmN384Params& p, int64_t tt0, bf16x8 (*img)[KSTEPS][64], float2* stats) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tg = wave & 3, nh = wave >> 2;
+  const int fg = wave & 3, th = wave >> 2;
   const int r = lane & 31, h = lane >> 5;
-  const bool valid = tg < n_valid;  // wave-uniform
-  const int64_t tt = tt0 + (valid ? tg : 0);
-  constexpr int KTOT = KS2 * KC2;  // k-steps per output tile
-  constexpr int NIT = KC2 * 3;     // iterations: (K chunk, pair of tiles)
-  // wl[buf][nh][t2][HTILE_VEC]
-  auto wtile = [&](int buf, int half, int t2) { return wl + ((buf * 2 + half) * 2 + t2) * HTILE_VEC; };
+  const unsigned lane16 = (unsigned)lane * 16u;
 
-  f32x16 acc[6];
+  {
+    const bf16x8* cs = p.x + frag_base(tt0, 0, KSTEPS) + lane;
+    bf16x8* flat = &img[0][0][0];
 #pragma unroll
-  for (int j = 0; j < 6; ++j) acc[j] = zero16();
-  for (int i = tid; i < H; i += 512) {
-    par[i] = p.bias[i];
-    par[H + i] = p.gamma[i];
-    par[2 * H + i] = p.beta[i];
+    for (int i = 0; i < 12; ++i) {
+      const int piece = wave + 8 * i;
+      glds16(cs + piece * 64, flat + piece * 64);
+    }
   }
-
-  // iteration it = (kc, jp): every feature half stages its tiles 6 nh + 2 jp + {0, 1}, K chunk kc.
-  // 4 half-tiles x 768 vectors = 3072 vectors = 6 per thread.
-  auto stage_src = [&](int it, int idx) {
-    const int kc = it / 3, jp = it - kc * 3;
-    const int half = idx / (2 * HTILE_VEC), rem = idx - half * (2 * HTILE_VEC);
-    const int t2 = rem / HTILE_VEC, off = rem - t2 * HTILE_VEC;
-    const int nt = half * 6 + jp * 2 + t2;
-    return p.w + ((int64_t)nt * KTOT + KS2 * kc) * 64 + off;
+  bf16x4 rr[3][2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const __bf16* res = p.resid + frag_base(tt0 + 2 * th + t, 0, KSTEPS) * 8;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        rr[j][t][g] = *reinterpret_cast<const bf16x4*>(
+            res + ((int64_t)((2 * (3 * fg + j) + (g >> 1)) * 64 + r + 32 * (g & 1))) * 8 + 4 * h);
+  }
+  // fragment f = 3 s + j (k-step s, tile 3 fg + j) lives in register f % WA
+  const __amdgpu_buffer_rsrc_t wrs = weight_rsrc(p.w);
+  constexpr int WA = 12, NFR = 3 * KSTEPS;
+  auto wfrag = [&](int f) {
+    const int s = f / 3, j = f - 3 * s;
+    return buffer_frag(wrs, lane16, (unsigned)(((3 * fg + j) * KSTEPS + s) * 1024));
   };
-  bf16x8 stage[6];
-  bf16x8* const lds_flat0 = wl;
-  bf16x8* const lds_flat1 = wl + 4 * HTILE_VEC;
-  // The block is latency-bound (a workgroup's MFMAs take ~4 us, the block ~12): every global load is
-  // requested one step before the step that needs it - the first activation chunk together with the
-  // first weight tiles, chunk kc + 1 during the last tile pair of chunk kc, the residual rows during
-  // the last tile pair of all.
-  const bf16x8* xs = p.x + frag_base(tt, 0, KTOT) + lane;
-  bf16x8 x[KC2][KS2];
+  bf16x8 a[WA];
 #pragma unroll
-  for (int s = 0; s < KS2; ++s) x[0][s] = xs[s * 64];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) lds_flat0[tid + 512 * i] = *stage_src(0, tid + 512 * i);
+  for (int i = 0; i < WA; ++i) a[i] = wfrag(i);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA pieces have landed (and everything requested with them)
   __syncthreads();
 
-  const __bf16* res = p.resid + frag_base(tt, 0, KSTEPS) * 8;
-  bf16x4 rr[6][4];
+  f32x16 acc[3][2];
+  {
+    const bf16x8* xl = &img[2 * th][0][lane];
+    constexpr int BR = 4, NS = 2 * KSTEPS;   // slot n = 2 s + t: context fragment (2 th + t, s)
+    auto xat = [](int n) { return ((n & 1) * KSTEPS + (n >> 1)) * 64; };
+    bf16x8 xb[BR];
 #pragma unroll
-  for (int kc = 0; kc < KC2; ++kc) {
+    for (int i = 0; i < BR - 1; ++i) xb[i] = xl[xat(i)];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int jp = 0; jp < 3; ++jp) {
-      const int it = kc * 3 + jp;
-      const int cur = it & 1;
-      const bool more = it + 1 < NIT;
-      asm volatile("" ::: "memory");  // compiler-only: keep each step's requests where they are written
-      if (more) {
+    for (int n = 0; n < NS; ++n) {
+      const int s = n >> 1, t = n & 1;
+      if (n + BR - 1 < NS) xb[(n + BR - 1) % BR] = xl[xat(n + BR - 1)];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) stage[i] = *stage_src(it + 1, tid + 512 * i);
-#ifdef SSKD_PRO_XNEXT_EARLY
-        if (jp == 2) {
+      for (int j = 0; j < 3; ++j)
+        acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(3 * s + j) % WA], xb[n % BR], s == 0 ? zero16() : acc[j][t], 0, 0, 0);
+      if (t == 1) {
 #pragma unroll
-          for (int s = 0; s < KS2; ++s) x[(kc + 1) % KC2][s] = xs[(KS2 * (kc + 1) + s) * 64];
-        }
-#endif
-      } else {
-#pragma unroll
-        for (int j = 0; j < 6; ++j)
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-            rr[j][g] = *reinterpret_cast<const bf16x4*>(
-                res + ((int64_t)((2 * (nh * 6 + j) + (g >> 1)) * 64 + r + 32 * (g & 1))) * 8 + 4 * h);
+        for (int j = 0; j < 3; ++j)
+          if (3 * s + j + WA < NFR) a[(3 * s + j) % WA] = wfrag(3 * s + j + WA);
       }
-      asm volatile("" ::: "memory");
-#ifndef SSKD_PRO_XNEXT_EARLY
-      if (jp == 0 && kc > 0) {
-#pragma unroll
-        for (int s = 0; s < KS2; ++s) x[kc][s] = xs[(KS2 * kc + s) * 64];
-      }
-#endif
-      acc[2 * jp] = tile_mfma<KS2, 4>(wtile(cur, nh, 0) + lane, x[kc], acc[2 * jp]);
-      acc[2 * jp + 1] = tile_mfma<KS2, 4>(wtile(cur, nh, 1) + lane, x[kc], acc[2 * jp + 1]);
-      if (more) {
-        bf16x8* dst = cur ? lds_flat0 : lds_flat1;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) dst[tid + 512 * i] = stage[i];
-      }
-      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
-  // epilogue: v = acc + bias + residual; LayerNorm over the token's 384 features, of which
-  // this lane holds 96, lane ^ 32 another 96 and the partner wave (other nh) the remaining 192
-  float sum = 0.f, sq = 0.f;
+  // v = acc + bias + residual; LayerNorm over the token's 384 features: 48 in this lane, 48 in lane ^ 32, 96 per wave
+  float sum[2] = {0.f, 0.f}, sq[2] = {0.f, 0.f};
 #pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const int nt = nh * 6 + j;
+  for (int j = 0; j < 3; ++j)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const f32x4 b = *reinterpret_cast<const f32x4*>(&par[nt * 32 + 8 * g + 4 * h]);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + (3 * fg + j) * 32 + 8 * g + 4 * h);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float v = acc[j][4 * g + e] + b[e] + bf2f(rr[j][g][e]);
-        acc[j][4 * g + e] = v;
-        sum += v;
-        sq = fmaf(v, v, sq);
-      }
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = acc[j][t][4 * g + e] + b[e] + bf2f(rr[j][t][g][e]);
+          acc[j][t][4 * g + e] = v;
+          sum[t] += v;
+          sq[t] = fmaf(v, v, sq[t]);
+        }
     }
-  }
-  sum = pair_sum(sum);
-  sq = pair_sum(sq);
-  if (h == 0) stats[(tg * 32 + r) * 2 + nh] = make_float2(sum, sq);
-  __syncthreads();
-  const float2 s0 = stats[(tg * 32 + r) * 2], s1 = stats[(tg * 32 + r) * 2 + 1];
-  const float mean = (s0.x + s1.x) * (1.0f / H);
-  const float var = fmaxf((s0.y + s1.y) * (1.0f / H) - mean * mean, 0.f);
-  const float rstd = rsqrtf(var + p.eps);
-  if (valid) {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const int nt = nh * 6 + j;
+  for (int t = 0; t < 2; ++t) {
+    const float s1 = pair_sum(sum[t]), s2 = pair_sum(sq[t]);
+    if (h == 0) stats[((2 * th + t) * 32 + r) * 4 + fg] = make_float2(s1, s2);
+  }
+  __syncthreads();   // the statistics are complete, and nobody reads the context image any more
+  float mean[2], rstd[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float2 st = stats[((2 * th + t) * 32 + r) * 4 + k];
+      s1 += st.x;
+      s2 += st.y;
+    }
+    mean[t] = s1 * (1.0f / H);
+    const float var = fmaxf(s2 * (1.0f / H) - mean[t] * mean[t], 0.f);
+    rstd[t] = rsqrtf(var + p.eps);
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int nt = 3 * fg + j;
+    f32x4 ga[4], be[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      ga[g] = *reinterpret_cast<const f32x4*>(p.gamma + nt * 32 + 8 * g + 4 * h);
+      be[g] = *reinterpret_cast<const f32x4*>(p.beta + nt * 32 + 8 * g + 4 * h);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
       f32x4 v[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 ga = *reinterpret_cast<const f32x4*>(&par[H + nt * 32 + 8 * g + 4 * h]);
-        const f32x4 be = *reinterpret_cast<const f32x4*>(&par[2 * H + nt * 32 + 8 * g + 4 * h]);
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[g][e] = (acc[j][4 * g + e] - mean) * rstd * ga[e] + be[e];
-      }
-      if (OUT_LDS) store_tile_frag(reinterpret_cast<__bf16*>(img + frag_base(tg, 2 * nt, KSTEPS)), v, lane);
-      else store_tile_frag(p.out + frag_base(tt, 2 * nt, KSTEPS) * 8, v, lane);
+        for (int e = 0; e < 4; ++e) v[g][e] = (acc[j][t][4 * g + e] - mean[t]) * rstd[t] * ga[g][e] + be[g][e];
+      store_tile_frag(reinterpret_cast<__bf16*>(&img[2 * th + t][2 * nt][0]), v, lane);
     }
   }
 }
@@ -464,15 +416,6 @@ __device__ unsigned long long g_probe[2][64][4];
 #define SSKD_STAMP(role, it, slot) do {} while (0)
 #endif
 
-// 16 B per lane through a buffer resource: wave-uniform fragment offset in an SGPR, one 32-bit lane offset - no 64-bit
-// address arithmetic and no address registers inside the bursts
-__device__ inline bf16x8 buffer_frag(__amdgpu_buffer_rsrc_t rs, unsigned lane16, unsigned byte_off) {
-  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, byte_off, 0));
-}
-__device__ inline __amdgpu_buffer_rsrc_t weight_rsrc(const void* base) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
-}
-
 // Workgroup = 8 waves = 128 tokens, WEIGHT-STATIONARY (round 4).  Every weight byte of a 128-hidden-unit super-chunk is
 // needed by exactly one wave and goes global -> registers; nothing is staged through LDS (the round-3 kernel kept X1 in
 // the producers' registers and walked both weight matrices through LDS: its ds_write_b128 staging was 16.6 % of the step).
@@ -508,7 +451,7 @@ __device__ inline __amdgpu_buffer_rsrc_t weight_rsrc(const void* base) {
 // (group order rotated by wave) and read those before the barrier too.
 //
 // FUSE_OUTPROJ: the attention output projection + residual + LayerNorm (X1) of the workgroup's 128 tokens runs as a
-// PROLOGUE (gemm_n384_ln_block; its 96-KiB weight staging area is the image's place, its scratch the raw buffer) and
+// PROLOGUE (outproj_ln_image: the context image takes the X1 image's place first, its scratch is the raw buffer) and
 // leaves X1 as the fragment-order image: X1 never reaches HBM.
 template <bool FUSE_OUTPROJ>
 __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
@@ -528,11 +471,8 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
   if constexpr (FUSE_OUTPROJ) {
-    static_assert(GEMM384_WL_VEC == 4 * KSTEPS * 64, "the projection's weight staging area is the image's place");
-    static_assert(sizeof(hraw) >= 128 * 2 * sizeof(float2) + 3 * H * sizeof(float), "prologue scratch");
-    float2* const stats = reinterpret_cast<float2*>(&hraw[0][0][0][0]);
-    float* const par = reinterpret_cast<float*>(stats + 128 * 2);
-    gemm_n384_ln_block<2, true>(p.outp, tile0, 4, &ximg[0][0][0], stats, par, &ximg[0][0][0]);
+    static_assert(sizeof(hraw) >= 128 * 4 * sizeof(float2), "prologue scratch");
+    outproj_ln_image(p.outp, tile0, ximg, reinterpret_cast<float2*>(&hraw[0][0][0][0]));
   } else {
     const bf16x8* xs = p.x1 + frag_base(tile0, 0, KSTEPS);
     bf16x8* xd = &ximg[0][0][0];
@@ -637,18 +577,25 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
 #endif
     // y starts as bias + residual (the image is X1): the epilogue is the LayerNorm alone
     f32x16 y[3][4];
+    f32x4 bb[2][4];   // b2 of feature tile j, requested one tile ahead (one L2 round trip per tile, not per accumulator)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bb[0][g] = *reinterpret_cast<const f32x4*>(p.b2 + fq * 96 + 8 * g + 4 * h);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int nt = fq * 3 + j;
+      if (j + 1 < 3) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bb[(j + 1) & 1][g] = *reinterpret_cast<const f32x4*>(p.b2 + (nt + 1) * 32 + 8 * g + 4 * h);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
         const __bf16* res = reinterpret_cast<const __bf16*>(&ximg[tt][0][0]);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(p.b2 + nt * 32 + 8 * g + 4 * h);
           const bf16x4 rr = *reinterpret_cast<const bf16x4*>(res + ((2 * nt + (g >> 1)) * 64 + r + 32 * (g & 1)) * 8 + 4 * h);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) y[j][tt][4 * g + e] = b[e] + bf2f(rr[e]);
+          for (int e = 0; e < 4; ++e) y[j][tt][4 * g + e] = bb[j & 1][g][e] + bf2f(rr[e]);
         }
         __builtin_amdgcn_sched_barrier(0);   // one tile at a time: hoisted loads would spill the accumulators for good
       }
@@ -750,6 +697,7 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
       if (h == 0) stats[(tt * 32 + r) * 4 + fq] = make_float2(sum, sq);
     }
     __syncthreads();
+    float mean[4], rstd[4];
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) {
       float sum = 0.f, sq = 0.f;
@@ -759,20 +707,26 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
         sum += t.x;
         sq += t.y;
       }
-      const float mean = sum * (1.0f / H);
-      const float var = fmaxf(sq * (1.0f / H) - mean * mean, 0.f);
-      const float rstd = rsqrtf(var + p.eps);
+      mean[tt] = sum * (1.0f / H);
+      const float var = fmaxf(sq * (1.0f / H) - mean[tt] * mean[tt], 0.f);
+      rstd[tt] = rsqrtf(var + p.eps);
+    }
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int nt = fq * 3 + j;
+    for (int j = 0; j < 3; ++j) {   // feature tile outermost: gamma / beta are fetched once per tile, not once per token tile
+      const int nt = fq * 3 + j;
+      f32x4 ga[4], be[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        ga[g] = *reinterpret_cast<const f32x4*>(p.gamma + nt * 32 + 8 * g + 4 * h);
+        be[g] = *reinterpret_cast<const f32x4*>(p.beta + nt * 32 + 8 * g + 4 * h);
+      }
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
         f32x4 v[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + nt * 32 + 8 * g + 4 * h);
-          const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + nt * 32 + 8 * g + 4 * h);
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[g][e] = (y[j][tt][4 * g + e] - mean) * rstd * ga[e] + be[e];
-        }
+          for (int e = 0; e < 4; ++e) v[g][e] = (y[j][tt][4 * g + e] - mean[tt]) * rstd[tt] * ga[g][e] + be[g][e];
         store_tile_frag(p.out + frag_base(tile0 + tt, 2 * nt, KSTEPS) * 8, v, lane);
       }
     }
@@ -1405,7 +1359,6 @@ int run_layers(const sskd_encoder_config* cfg, const sskd_encoder_weights* w, co
     o.gamma = lw.ln1_g;
     o.beta = lw.ln1_b;
     o.eps = cfg->layer_norm_eps;
-    o.out = nullptr;  // X1 stays in the fused MLP's LDS
     auto qa_kernel = nkt > 8 ? qkv_attention_kernel<true, false>
                              : (d_seg ? qkv_attention_kernel<false, true> : qkv_attention_kernel<false, false>);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(qa_kernel),
