@@ -28,6 +28,7 @@
 //                           X2 = LN(X1 + gelu(X1 W1^T + b1) W2^T + b2)       (hidden 1536 stays on chip)
 #include "common.h"
 
+#include <algorithm>
 #include <type_traits>
 #include <vector>
 
@@ -238,6 +239,15 @@ __device__ inline __amdgpu_buffer_rsrc_t weight_rsrc(const void* base) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
 }
 
+// The context rows of token tiles tt0 .. tt0 + 3 -> `img` by LDS-DMA: 96 pieces of 1 KiB, dealt to `n_waves` waves
+// (this one is number `w`).  The caller waits (vmcnt) and synchronises the workgroup before anybody reads the image.
+__device__ inline void request_context_image(const GemmN384Params& p, int64_t tt0, bf16x8 (*img)[KSTEPS][64], int w,
+                                             int n_waves, int lane) {
+  const bf16x8* cs = p.x + frag_base(tt0, 0, KSTEPS) + lane;
+  bf16x8* flat = &img[0][0][0];
+  for (int piece = w; piece < 4 * KSTEPS; piece += n_waves) glds16(cs + piece * 64, flat + piece * 64);
+}
+
 // Prologue of the fused MLP: X1 = LN(resid + ctx Wo^T + bo) for the 4 token tiles tt0 .. tt0 + 3 of a 512-thread
 // workgroup, left as the fragment-order image `img` (96 KiB of LDS).  Weight-stationary like the MLP itself (round 4):
 //   - the context rows arrive as a fragment-order image by LDS-DMA (96 pieces of 1 KiB, no registers), the residual rows
@@ -251,24 +261,16 @@ __device__ inline __amdgpu_buffer_rsrc_t weight_rsrc(const void* base) {
 //     `stats` ([128 tokens][4 groups], 4 KiB), behind the barrier that also ends everybody's reads of the context image;
 //     the normalised rows then overwrite it.
 // Every wave of the workgroup must call this (two workgroup barriers inside); the caller adds the one that completes
-// the image.
-__device__ inline void outproj_ln_image(const GemmN384Params& p, int64_t tt0, bf16x8 (*img)[KSTEPS][64], float2* stats) {
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+// the image.  `ctx_requested`: the DMA pieces were requested earlier (the persistent workgroup's previous tail);
+// `lane`: the caller's (per-group, opaque) lane id.
+__device__ inline void outproj_ln_image(const GemmN384Params& p, int64_t tt0, bf16x8 (*img)[KSTEPS][64], float2* stats,
+                                        bool ctx_requested, int lane) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int fg = wave & 3, th = wave >> 2;
   const int r = lane & 31, h = lane >> 5;
   const unsigned lane16 = (unsigned)lane * 16u;
 
-  {
-    const bf16x8* cs = p.x + frag_base(tt0, 0, KSTEPS) + lane;
-    bf16x8* flat = &img[0][0][0];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      const int piece = wave + 8 * i;
-      glds16(cs + piece * 64, flat + piece * 64);
-    }
-  }
+  if (!ctx_requested) request_context_image(p, tt0, img, wave, 8, lane);
   bf16x4 rr[3][2][4];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -391,6 +393,7 @@ struct MlpParams {
   float eps;
   __bf16* out;           // fragment-order [T_pad, 384]
   GemmN384Params outp;   // FUSE_OUTPROJ: X1 = LN(X + ctx Wo^T + bo) is computed in the prologue
+  int n_groups;          // T_pad / 128: groups of 128 tokens, walked by gridDim.x persistent workgroups
 };
 
 constexpr int MLP_SUPER = FF / 128;  // 12 super-chunks of 128 hidden units
@@ -458,279 +461,311 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
   __shared__ bf16x8 ximg[4][KSTEPS][64];          // X1 of the workgroup's 128 tokens, fragment order: 96 KiB
   __shared__ bf16x8 hh[2][4][4][64];              // h fragments [k-step s2][hidden tile][token tile][lane]: 32 KiB
   __shared__ f32x4 hraw[4][4][2][64];             // the consumers' half of the GELU work, fp32 (bias added): 32 KiB
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const bool producer = wave < 4;  // wave-uniform
   const int pq = wave & 3;
-  const int r = lane & 31, h = lane >> 5;
-  const int64_t tile0 = (int64_t)blockIdx.x * 4;
-  const unsigned lane16 = (unsigned)lane * 16u;
 
 #ifdef SSKD_PROBE   // [60] = {start, image complete, loop entered, loop left}, [61][0] = end
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
-  if constexpr (FUSE_OUTPROJ) {
-    static_assert(sizeof(hraw) >= 128 * 4 * sizeof(float2), "prologue scratch");
-    outproj_ln_image(p.outp, tile0, ximg, reinterpret_cast<float2*>(&hraw[0][0][0][0]));
-  } else {
-    const bf16x8* xs = p.x1 + frag_base(tile0, 0, KSTEPS);
-    bf16x8* xd = &ximg[0][0][0];
-    for (int i = tid; i < 4 * KSTEPS * 64; i += 512) xd[i] = xs[i];
-  }
-  __syncthreads();  // the X1 image is complete
-
-  // From here on the two roles never share code: the producers' 96 registers of W1 fragments and the consumers' 192
-  // accumulators must not be live in one block.  Both branches execute the same number of workgroup barriers
-  // (2 MLP_SUPER + 3).
+  // PERSISTENT workgroup: groups blockIdx.x, blockIdx.x + gridDim.x, ... of 128 tokens.  A workgroup's first and last
+  // ~30 % are memory bursts that nothing else on its CU overlaps (one workgroup per CU); walking several groups lets the
+  // producers, idle while the consumers finish a group, request the NEXT group's context image under that tail.
+  // The two roles never share code, not even the loop over groups: the producers' 96 registers of W1 fragments and the
+  // consumers' 192 accumulators must not be live in one block, and a loop body without role branches is what the register
+  // allocator keeps spill-free.  Both branches execute the same workgroup barriers (3 + 2 MLP_SUPER + 3 per group).
   if (producer) {
-    const int hp = pq;
-    SSKD_STAMP(0, 60, 1);
-#ifdef SSKD_PROBE
-    if (blockIdx.x == 0 && pq == 0 && lane == 0) g_probe[0][60][0] = t_begin;
-#endif
-    const __amdgpu_buffer_rsrc_t w1rs = weight_rsrc(p.w1);
-    bf16x8 w[KSTEPS];
-#pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) w[s] = buffer_frag(w1rs, lane16, (unsigned)((hp * KSTEPS + s) * 1024));
-    f32x4 bias[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bias[g] = *reinterpret_cast<const f32x4*>(p.b1 + hp * 32 + 8 * g + 4 * h);
-    bf16x8 fd[4];   // this wave's finished half of the previous super-chunk
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) fd[tt] = zero_bf8();
-    const bf16x8* xl = &ximg[0][0][lane];
-    // slot n = 4 s + tt of a burst multiplies fragment (tt, s) of the image
-    constexpr int XR = SSKD_MLP_XR, NS = 4 * KSTEPS;
-    auto xat = [](int n) { return ((n & 3) * KSTEPS + (n >> 2)) * 64; };
-    bf16x8 xb[XR];
-#pragma unroll
-    for (int i = 0; i < XR - 1; ++i) xb[i] = xl[xat(i)];
-    SSKD_STAMP(0, 60, 2);
-    for (int it = 0; it < MLP_SUPER; ++it) {   // the consumers run one iteration behind (their last one is peeled below)
-      f32x16 acc[4];
-      SSKD_STAMP(0, it, 0);
-      {
-        const unsigned wnext = (unsigned)(((it + 1 < MLP_SUPER ? it + 1 : it) * 4 + hp) * KSTEPS * 1024);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(3);
-#pragma unroll
-        for (int n = 0; n < NS; ++n) {
-          const int s = n >> 2, tt = n & 3;
-          if (n + XR - 1 < NS) xb[(n + XR - 1) % XR] = xl[xat(n + XR - 1)];
-          acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[s], xb[n % XR], s == 0 ? zero16() : acc[tt], 0, 0, 0);
-          if (n < 4) hh[0][hp][n][lane] = fd[n];   // the finished half of the previous super-chunk, behind the first MFMAs
-          if (tt == 3) w[s] = buffer_frag(w1rs, lane16, wnext + s * 1024);   // last use: fetch the next super-chunk's
-          __builtin_amdgcn_sched_barrier(0);   // one slot = one MFMA: keeps every request where it is written
-        }
-        __builtin_amdgcn_s_setprio(0);
+    for (int grp = blockIdx.x; grp < p.n_groups; grp += gridDim.x) {
+      // the lane id is re-derived per group through an opaque copy: otherwise every per-lane address of the body (a dozen
+      // 64-bit pointers) is hoisted out of this loop and lives - spilled - across all of it
+      int tid = threadIdx.x;
+      asm volatile("" : "+v"(tid));
+      const int lane = tid & 63, r = lane & 31, h = lane >> 5;
+      const unsigned lane16 = (unsigned)lane * 16u;
+      const int64_t tile0 = (int64_t)grp * 4;
+      const bool has_next = grp + (int)gridDim.x < p.n_groups;
+      if constexpr (FUSE_OUTPROJ) {
+        static_assert(sizeof(hraw) >= 128 * 4 * sizeof(float2), "prologue scratch");
+        outproj_ln_image(p.outp, tile0, ximg, reinterpret_cast<float2*>(&hraw[0][0][0][0]), grp != (int)blockIdx.x, lane);
+      } else {
+        const bf16x8* xs = p.x1 + frag_base(tile0, 0, KSTEPS);
+        bf16x8* xd = &ximg[0][0][0];
+        for (int i = tid; i < 4 * KSTEPS * 64; i += 512) xd[i] = xs[i];
       }
-      SSKD_STAMP(0, it, 1);
-      __builtin_amdgcn_sched_barrier(0);   // the GELU belongs behind the barrier (the consumers' burst waits on it)
-      __syncthreads();
-      __builtin_amdgcn_sched_barrier(0);
-      SSKD_STAMP(0, it, 2);
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) fd[tt][i] = (__bf16)gelu_erf(acc[tt][i] + bias[i >> 2][i & 3]);
-        f32x4 r0, r1;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          r0[e] = acc[tt][8 + e] + bias[2][e];
-          r1[e] = acc[tt][12 + e] + bias[3][e];
-        }
-        hraw[hp][tt][0][lane] = r0;
-        hraw[hp][tt][1][lane] = r1;
-      }
-      // pin the finished values here, or the compiler sinks their whole computation past the barrier into the burst
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        u32x4 t = __builtin_bit_cast(u32x4, fd[tt]);
-        asm volatile("" : "+v"(t));
-        fd[tt] = __builtin_bit_cast(bf16x8, t);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      {   // the next super-chunk's bias and the ring's first fragments: both a whole phase ahead of their use
-        const int nx = it + 1 < MLP_SUPER ? it + 1 : it;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bias[g] = *reinterpret_cast<const f32x4*>(p.b1 + nx * 128 + hp * 32 + 8 * g + 4 * h);
-#pragma unroll
-        for (int i = 0; i < XR - 1; ++i) xb[i] = xl[xat(i)];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      SSKD_STAMP(0, it, 3);
-      __syncthreads();
-    }
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) hh[0][hp][tt][lane] = fd[tt];
-    SSKD_STAMP(0, 60, 3);
-    __syncthreads();
-    __syncthreads();
-    __syncthreads();   // the consumers' LayerNorm statistics meet behind this barrier
-    SSKD_STAMP(0, 61, 0);
-  } else {
-    const int fq = pq;
-    SSKD_STAMP(1, 60, 1);
-#ifdef SSKD_PROBE
-    if (blockIdx.x == 0 && pq == 0 && lane == 0) g_probe[1][60][0] = t_begin;
-#endif
-    // y starts as bias + residual (the image is X1): the epilogue is the LayerNorm alone
-    f32x16 y[3][4];
-    f32x4 bb[2][4];   // b2 of feature tile j, requested one tile ahead (one L2 round trip per tile, not per accumulator)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bb[0][g] = *reinterpret_cast<const f32x4*>(p.b2 + fq * 96 + 8 * g + 4 * h);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int nt = fq * 3 + j;
-      if (j + 1 < 3) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bb[(j + 1) & 1][g] = *reinterpret_cast<const f32x4*>(p.b2 + (nt + 1) * 32 + 8 * g + 4 * h);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        const __bf16* res = reinterpret_cast<const __bf16*>(&ximg[tt][0][0]);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const bf16x4 rr = *reinterpret_cast<const bf16x4*>(res + ((2 * nt + (g >> 1)) * 64 + r + 32 * (g & 1)) * 8 + 4 * h);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) y[j][tt][4 * g + e] = bb[j & 1][g][e] + bf2f(rr[e]);
-        }
-        __builtin_amdgcn_sched_barrier(0);   // one tile at a time: hoisted loads would spill the accumulators for good
-      }
-    }
-    // Group order of this wave: position cs -> (hidden tile cc, k-step s2) = (cs + 2 fq + 1) mod 8, i.e. it starts with
-    // the fragments (fq, 1) this wave wrote itself in phase 1.  Fragment f = 3 cs + j of super-chunk sc is
-    // w2p[(((4 sc + cc) * 12 + 3 fq + j) * 2 + s2) * 64 + lane]; 24 fragments per super-chunk walk through 9 registers,
-    // the sequence padded to 27 so that fragment f always lives in register f % 9.
-    const __amdgpu_buffer_rsrc_t w2rs = weight_rsrc(p.w2p);
-    const int rot = 2 * fq + 1;
-    auto frag_ld = [&](int sc, int f) {
-      const int cs = f / 3, j = f - cs * 3, csr = (cs + rot) & 7, cc = csr >> 1, s2 = csr & 1;
-      return buffer_frag(w2rs, lane16, (unsigned)((((4 * sc + cc) * 12 + 3 * fq + j) * 2 + s2) * 1024));
-    };
-    constexpr int NF = 24;
-    bf16x8 a[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) a[i] = frag_ld(0, i);
-    __syncthreads();   // iteration 0: nothing to consume yet
-    __syncthreads();
-    for (int it = 1; it <= MLP_SUPER; ++it) {
-      SSKD_STAMP(1, it, 0);
-      // phase 1: GELU of this wave's share (hidden tile fq, k-step 1) of the previous super-chunk's raw half
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {   // four values at a time: 192 accumulators leave ~25 registers for this
-        bf16x8 f;
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-          const f32x4 rw = hraw[fq][tt][hf][lane];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) f[4 * hf + e] = (__bf16)gelu_erf(rw[e]);
+      __syncthreads();  // the X1 image is complete
+      const int hp = pq;
+      SSKD_STAMP(0, 60, 1);
+  #ifdef SSKD_PROBE
+      if (blockIdx.x == 0 && pq == 0 && lane == 0) g_probe[0][60][0] = t_begin;
+  #endif
+      const __amdgpu_buffer_rsrc_t w1rs = weight_rsrc(p.w1);
+      bf16x8 w[KSTEPS];
+  #pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) w[s] = buffer_frag(w1rs, lane16, (unsigned)((hp * KSTEPS + s) * 1024));
+      f32x4 bias[4];
+  #pragma unroll
+      for (int g = 0; g < 4; ++g) bias[g] = *reinterpret_cast<const f32x4*>(p.b1 + hp * 32 + 8 * g + 4 * h);
+      bf16x8 fd[4];   // this wave's finished half of the previous super-chunk
+  #pragma unroll
+      for (int tt = 0; tt < 4; ++tt) fd[tt] = zero_bf8();
+      const bf16x8* xl = &ximg[0][0][lane];
+      // slot n = 4 s + tt of a burst multiplies fragment (tt, s) of the image
+      constexpr int XR = SSKD_MLP_XR, NS = 4 * KSTEPS;
+      auto xat = [](int n) { return ((n & 3) * KSTEPS + (n >> 2)) * 64; };
+      bf16x8 xb[XR];
+  #pragma unroll
+      for (int i = 0; i < XR - 1; ++i) xb[i] = xl[xat(i)];
+      SSKD_STAMP(0, 60, 2);
+      for (int it = 0; it < MLP_SUPER; ++it) {   // the consumers run one iteration behind (their last one is peeled below)
+        f32x16 acc[4];
+        SSKD_STAMP(0, it, 0);
+        {
+          const unsigned wnext = (unsigned)(((it + 1 < MLP_SUPER ? it + 1 : it) * 4 + hp) * KSTEPS * 1024);
           __builtin_amdgcn_sched_barrier(0);
-        }
-        hh[1][fq][tt][lane] = f;
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // the burst walks (group cs, token tile tt); a group's three W2 fragments stay in registers while the four token
-      // tiles' h fragments stream through a ring of HR (one LDS read per three MFMAs, two reads ahead)
-      constexpr int HR = 3;
-      const bf16x8* hl = &hh[0][0][0][lane];
-      auto hidx = [&](int g) {
-        const int csr = ((g >> 2) + rot) & 7, tt = g & 3;
-        return ((csr & 1) * 16 + (csr >> 1) * 4 + tt) * 64;
-      };
-      bf16x8 hb[HR];
-#pragma unroll
-      for (int i = 0; i < HR - 1; ++i) hb[i] = hl[hidx(i)];   // own fragments (same wave: ordered behind the writes above)
-      __builtin_amdgcn_sched_barrier(0);
-      SSKD_STAMP(1, it, 3);
-      __syncthreads();
-      SSKD_STAMP(1, it, 1);
-      {
-        const int sc = it - 1;
-        const int scn = sc + 1 < MLP_SUPER ? sc + 1 : sc;
-        __builtin_amdgcn_s_setprio(3);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int g = 0; g < 32; ++g) {
-          const int cs = g >> 2, tt = g & 3;
-          if (g + HR - 1 < 32) hb[(g + HR - 1) % HR] = hl[hidx(g + HR - 1)];
-#pragma unroll
-          for (int j = 0; j < 3; ++j)
-            y[j][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(cs * 3 + j) % 9], hb[g % HR], y[j][tt], 0, 0, 0);
-          if (tt == 3) {   // the group is finished: refill its registers (f + 9 < 24: this super-chunk's fragment f + 9;
-                           // f + 9 >= 27: the next one's fragment f - 18)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-              const int f = cs * 3 + j, fn = f + 9;
-              if (fn < NF) a[f % 9] = frag_ld(sc, fn);
-              else if (fn >= 27) a[f % 9] = frag_ld(scn, fn - 27);
-            }
-            if (cs == 7) {   // the pad: fragments 6 .. 8 of the next super-chunk
-#pragma unroll
-              for (int j = 6; j < 9; ++j) a[j] = frag_ld(scn, j);
-            }
+          __builtin_amdgcn_s_setprio(3);
+  #pragma unroll
+          for (int n = 0; n < NS; ++n) {
+            const int s = n >> 2, tt = n & 3;
+            if (n + XR - 1 < NS) xb[(n + XR - 1) % XR] = xl[xat(n + XR - 1)];
+            acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[s], xb[n % XR], s == 0 ? zero16() : acc[tt], 0, 0, 0);
+            if (n < 4) hh[0][hp][n][lane] = fd[n];   // the finished half of the previous super-chunk, behind the first MFMAs
+            if (tt == 3) w[s] = buffer_frag(w1rs, lane16, wnext + s * 1024);   // last use: fetch the next super-chunk's
+            __builtin_amdgcn_sched_barrier(0);   // one slot = one MFMA: keeps every request where it is written
           }
+          __builtin_amdgcn_s_setprio(0);
+        }
+        SSKD_STAMP(0, it, 1);
+        __builtin_amdgcn_sched_barrier(0);   // the GELU belongs behind the barrier (the consumers' burst waits on it)
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        SSKD_STAMP(0, it, 2);
+  #pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+  #pragma unroll
+          for (int i = 0; i < 8; ++i) fd[tt][i] = (__bf16)gelu_erf(acc[tt][i] + bias[i >> 2][i & 3]);
+          f32x4 r0, r1;
+  #pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            r0[e] = acc[tt][8 + e] + bias[2][e];
+            r1[e] = acc[tt][12 + e] + bias[3][e];
+          }
+          hraw[hp][tt][0][lane] = r0;
+          hraw[hp][tt][1][lane] = r1;
+        }
+        // pin the finished values here, or the compiler sinks their whole computation past the barrier into the burst
+  #pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          u32x4 t = __builtin_bit_cast(u32x4, fd[tt]);
+          asm volatile("" : "+v"(t));
+          fd[tt] = __builtin_bit_cast(bf16x8, t);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {   // the next super-chunk's bias and the ring's first fragments: both a whole phase ahead of their use
+          const int nx = it + 1 < MLP_SUPER ? it + 1 : it;
+  #pragma unroll
+          for (int g = 0; g < 4; ++g) bias[g] = *reinterpret_cast<const f32x4*>(p.b1 + nx * 128 + hp * 32 + 8 * g + 4 * h);
+  #pragma unroll
+          for (int i = 0; i < XR - 1; ++i) xb[i] = xl[xat(i)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        SSKD_STAMP(0, it, 3);
+        __syncthreads();
+      }
+  #pragma unroll
+      for (int tt = 0; tt < 4; ++tt) hh[0][hp][tt][lane] = fd[tt];
+      SSKD_STAMP(0, 60, 3);
+      // nobody reads the X1 image any more (the consumers took the residual at their set-up): the next group's context rows
+      // can land in its place while the consumers run their last burst and the LayerNorm
+      if (FUSE_OUTPROJ && has_next)
+        request_context_image(p.outp, (int64_t)(grp + (int)gridDim.x) * 4, ximg, hp, 4, lane);
+      __syncthreads();
+      __syncthreads();
+      __syncthreads();   // the consumers' LayerNorm statistics meet behind this barrier
+      SSKD_STAMP(0, 61, 0);
+      if (!FUSE_OUTPROJ && has_next) __syncthreads();   // the consumers are done with the image before the next one is copied in
+    }   // groups
+  } else {
+    for (int grp = blockIdx.x; grp < p.n_groups; grp += gridDim.x) {
+      // the lane id is re-derived per group through an opaque copy: otherwise every per-lane address of the body (a dozen
+      // 64-bit pointers) is hoisted out of this loop and lives - spilled - across all of it
+      int tid = threadIdx.x;
+      asm volatile("" : "+v"(tid));
+      const int lane = tid & 63, r = lane & 31, h = lane >> 5;
+      const unsigned lane16 = (unsigned)lane * 16u;
+      const int64_t tile0 = (int64_t)grp * 4;
+      const bool has_next = grp + (int)gridDim.x < p.n_groups;
+      if constexpr (FUSE_OUTPROJ) {
+        static_assert(sizeof(hraw) >= 128 * 4 * sizeof(float2), "prologue scratch");
+        outproj_ln_image(p.outp, tile0, ximg, reinterpret_cast<float2*>(&hraw[0][0][0][0]), grp != (int)blockIdx.x, lane);
+      } else {
+        const bf16x8* xs = p.x1 + frag_base(tile0, 0, KSTEPS);
+        bf16x8* xd = &ximg[0][0][0];
+        for (int i = tid; i < 4 * KSTEPS * 64; i += 512) xd[i] = xs[i];
+      }
+      __syncthreads();  // the X1 image is complete
+      const int fq = pq;
+      SSKD_STAMP(1, 60, 1);
+  #ifdef SSKD_PROBE
+      if (blockIdx.x == 0 && pq == 0 && lane == 0) g_probe[1][60][0] = t_begin;
+  #endif
+      // y starts as bias + residual (the image is X1): the epilogue is the LayerNorm alone
+      f32x16 y[3][4];
+      f32x4 bb[2][4];   // b2 of feature tile j, requested one tile ahead (one L2 round trip per tile, not per accumulator)
+  #pragma unroll
+      for (int g = 0; g < 4; ++g) bb[0][g] = *reinterpret_cast<const f32x4*>(p.b2 + fq * 96 + 8 * g + 4 * h);
+  #pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int nt = fq * 3 + j;
+        if (j + 1 < 3) {
+  #pragma unroll
+          for (int g = 0; g < 4; ++g) bb[(j + 1) & 1][g] = *reinterpret_cast<const f32x4*>(p.b2 + (nt + 1) * 32 + 8 * g + 4 * h);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          const __bf16* res = reinterpret_cast<const __bf16*>(&ximg[tt][0][0]);
+  #pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const bf16x4 rr = *reinterpret_cast<const bf16x4*>(res + ((2 * nt + (g >> 1)) * 64 + r + 32 * (g & 1)) * 8 + 4 * h);
+  #pragma unroll
+            for (int e = 0; e < 4; ++e) y[j][tt][4 * g + e] = bb[j & 1][g][e] + bf2f(rr[e]);
+          }
+          __builtin_amdgcn_sched_barrier(0);   // one tile at a time: hoisted loads would spill the accumulators for good
+        }
+      }
+      // Group order of this wave: position cs -> (hidden tile cc, k-step s2) = (cs + 2 fq + 1) mod 8, i.e. it starts with
+      // the fragments (fq, 1) this wave wrote itself in phase 1.  Fragment f = 3 cs + j of super-chunk sc is
+      // w2p[(((4 sc + cc) * 12 + 3 fq + j) * 2 + s2) * 64 + lane]; 24 fragments per super-chunk walk through 9 registers,
+      // the sequence padded to 27 so that fragment f always lives in register f % 9.
+      const __amdgpu_buffer_rsrc_t w2rs = weight_rsrc(p.w2p);
+      const int rot = 2 * fq + 1;
+      auto frag_ld = [&](int sc, int f) {
+        const int cs = f / 3, j = f - cs * 3, csr = (cs + rot) & 7, cc = csr >> 1, s2 = csr & 1;
+        return buffer_frag(w2rs, lane16, (unsigned)((((4 * sc + cc) * 12 + 3 * fq + j) * 2 + s2) * 1024));
+      };
+      constexpr int NF = 24;
+      bf16x8 a[9];
+  #pragma unroll
+      for (int i = 0; i < 9; ++i) a[i] = frag_ld(0, i);
+      __syncthreads();   // iteration 0: nothing to consume yet
+      __syncthreads();
+      for (int it = 1; it <= MLP_SUPER; ++it) {
+        SSKD_STAMP(1, it, 0);
+        // phase 1: GELU of this wave's share (hidden tile fq, k-step 1) of the previous super-chunk's raw half
+  #pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {   // four values at a time: 192 accumulators leave ~25 registers for this
+          bf16x8 f;
+  #pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const f32x4 rw = hraw[fq][tt][hf][lane];
+  #pragma unroll
+            for (int e = 0; e < 4; ++e) f[4 * hf + e] = (__bf16)gelu_erf(rw[e]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          hh[1][fq][tt][lane] = f;
           __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_s_setprio(0);
-      }
-      SSKD_STAMP(1, it, 2);
-      __syncthreads();
-    }
-    // epilogue: LayerNorm over the token's 384 features - 48 in this lane, 48 in lane ^ 32, 96 per consumer
-    SSKD_STAMP(1, 60, 3);
-    float2* const stats = reinterpret_cast<float2*>(&hraw[0][0][0][0]);   // dead by now: [128 tokens][4 consumers]
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-      float sum = 0.f, sq = 0.f;
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          sum += y[j][tt][i];
-          sq = fmaf(y[j][tt][i], y[j][tt][i], sq);
+        // the burst walks (group cs, token tile tt); a group's three W2 fragments stay in registers while the four token
+        // tiles' h fragments stream through a ring of HR (one LDS read per three MFMAs, two reads ahead)
+        constexpr int HR = 3;
+        const bf16x8* hl = &hh[0][0][0][lane];
+        auto hidx = [&](int g) {
+          const int csr = ((g >> 2) + rot) & 7, tt = g & 3;
+          return ((csr & 1) * 16 + (csr >> 1) * 4 + tt) * 64;
+        };
+        bf16x8 hb[HR];
+  #pragma unroll
+        for (int i = 0; i < HR - 1; ++i) hb[i] = hl[hidx(i)];   // own fragments (same wave: ordered behind the writes above)
+        __builtin_amdgcn_sched_barrier(0);
+        SSKD_STAMP(1, it, 3);
+        __syncthreads();
+        SSKD_STAMP(1, it, 1);
+        {
+          const int sc = it - 1;
+          const int scn = sc + 1 < MLP_SUPER ? sc + 1 : sc;
+          __builtin_amdgcn_s_setprio(3);
+          __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+          for (int g = 0; g < 32; ++g) {
+            const int cs = g >> 2, tt = g & 3;
+            if (g + HR - 1 < 32) hb[(g + HR - 1) % HR] = hl[hidx(g + HR - 1)];
+  #pragma unroll
+            for (int j = 0; j < 3; ++j)
+              y[j][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(cs * 3 + j) % 9], hb[g % HR], y[j][tt], 0, 0, 0);
+            if (tt == 3) {   // the group is finished: refill its registers (f + 9 < 24: this super-chunk's fragment f + 9;
+                             // f + 9 >= 27: the next one's fragment f - 18)
+  #pragma unroll
+              for (int j = 0; j < 3; ++j) {
+                const int f = cs * 3 + j, fn = f + 9;
+                if (fn < NF) a[f % 9] = frag_ld(sc, fn);
+                else if (fn >= 27) a[f % 9] = frag_ld(scn, fn - 27);
+              }
+              if (cs == 7) {   // the pad: fragments 6 .. 8 of the next super-chunk
+  #pragma unroll
+                for (int j = 6; j < 9; ++j) a[j] = frag_ld(scn, j);
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          __builtin_amdgcn_s_setprio(0);
         }
-      sum = pair_sum(sum);
-      sq = pair_sum(sq);
-      if (h == 0) stats[(tt * 32 + r) * 4 + fq] = make_float2(sum, sq);
-    }
-    __syncthreads();
-    float mean[4], rstd[4];
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-      float sum = 0.f, sq = 0.f;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float2 t = stats[(tt * 32 + r) * 4 + k];
-        sum += t.x;
-        sq += t.y;
+        SSKD_STAMP(1, it, 2);
+        __syncthreads();
       }
-      mean[tt] = sum * (1.0f / H);
-      const float var = fmaxf(sq * (1.0f / H) - mean[tt] * mean[tt], 0.f);
-      rstd[tt] = rsqrtf(var + p.eps);
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {   // feature tile outermost: gamma / beta are fetched once per tile, not once per token tile
-      const int nt = fq * 3 + j;
-      f32x4 ga[4], be[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        ga[g] = *reinterpret_cast<const f32x4*>(p.gamma + nt * 32 + 8 * g + 4 * h);
-        be[g] = *reinterpret_cast<const f32x4*>(p.beta + nt * 32 + 8 * g + 4 * h);
-      }
-#pragma unroll
+      // epilogue: LayerNorm over the token's 384 features - 48 in this lane, 48 in lane ^ 32, 96 per consumer
+      SSKD_STAMP(1, 60, 3);
+      float2* const stats = reinterpret_cast<float2*>(&hraw[0][0][0][0]);   // dead by now: [128 tokens][4 consumers]
+  #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
-        f32x4 v[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[g][e] = (y[j][tt][4 * g + e] - mean[tt]) * rstd[tt] * ga[g][e] + be[g][e];
-        store_tile_frag(p.out + frag_base(tile0 + tt, 2 * nt, KSTEPS) * 8, v, lane);
+        float sum = 0.f, sq = 0.f;
+  #pragma unroll
+        for (int j = 0; j < 3; ++j)
+  #pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            sum += y[j][tt][i];
+            sq = fmaf(y[j][tt][i], y[j][tt][i], sq);
+          }
+        sum = pair_sum(sum);
+        sq = pair_sum(sq);
+        if (h == 0) stats[(tt * 32 + r) * 4 + fq] = make_float2(sum, sq);
       }
-    }
-    SSKD_STAMP(1, 61, 0);
+      __syncthreads();
+      float mean[4], rstd[4];
+  #pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        float sum = 0.f, sq = 0.f;
+  #pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float2 t = stats[(tt * 32 + r) * 4 + k];
+          sum += t.x;
+          sq += t.y;
+        }
+        mean[tt] = sum * (1.0f / H);
+        const float var = fmaxf(sq * (1.0f / H) - mean[tt] * mean[tt], 0.f);
+        rstd[tt] = rsqrtf(var + p.eps);
+      }
+  #pragma unroll
+      for (int j = 0; j < 3; ++j) {   // feature tile outermost: gamma / beta are fetched once per tile, not once per token tile
+        const int nt = fq * 3 + j;
+        f32x4 ga[4], be[4];
+  #pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          ga[g] = *reinterpret_cast<const f32x4*>(p.gamma + nt * 32 + 8 * g + 4 * h);
+          be[g] = *reinterpret_cast<const f32x4*>(p.beta + nt * 32 + 8 * g + 4 * h);
+        }
+  #pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          f32x4 v[4];
+  #pragma unroll
+          for (int g = 0; g < 4; ++g)
+  #pragma unroll
+            for (int e = 0; e < 4; ++e) v[g][e] = (y[j][tt][4 * g + e] - mean[tt]) * rstd[tt] * ga[g][e] + be[g][e];
+          store_tile_frag(p.out + frag_base(tile0 + tt, 2 * nt, KSTEPS) * 8, v, lane);
+        }
+      }
+      SSKD_STAMP(1, 61, 0);
+      if (!FUSE_OUTPROJ && has_next) __syncthreads();
+    }   // groups
   }
 }
 
@@ -1312,12 +1347,25 @@ int check_cfg(const sskd_encoder_config* cfg, const sskd_encoder_weights* w, int
   return SSKD_OK;
 }
 
+// compute units of the current device (the persistent fused MLP launches one workgroup per CU)
+int cu_count() {
+  static int cached[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    int n = 0;
+    cached[dev] = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0 ? n : 256;
+  }
+  return cached[dev];
+}
+
 // runs embeddings + all layers; returns the (fragment-order) buffer holding the final hidden states
 int run_layers(const sskd_encoder_config* cfg, const sskd_encoder_weights* w, const int32_t* d_ids,
                const int32_t* d_mask, int B, int S, const Workspace& ws, hipStream_t st,
                __bf16** final_hidden, const int32_t* d_seg = nullptr) {
   const int Sp = s_pad_of(S), nkt = Sp / 32;
   const int Tpad = (int)t_pad_of(B, S);
+  const int n_cus = cu_count();
   hipLaunchKernelGGL(embed_ln_kernel, dim3(Tpad / 32), dim3(256), 0, st, d_ids,
                      static_cast<const bf16x8*>(w->word_emb), static_cast<const bf16x8*>(w->pos_emb),
                      static_cast<const bf16x8*>(w->type_emb), w->emb_ln_g, w->emb_ln_b, B, S, Sp,
@@ -1382,7 +1430,8 @@ int run_layers(const sskd_encoder_config* cfg, const sskd_encoder_weights* w, co
     m.eps = cfg->layer_norm_eps;
     m.out = x;
     m.outp = o;
-    hipLaunchKernelGGL(fused_mlp_ln_kernel<true>, dim3(Tpad / 128), dim3(512), 0, st, m);
+    m.n_groups = (int)(Tpad / 128);
+    hipLaunchKernelGGL(fused_mlp_ln_kernel<true>, dim3(std::min(m.n_groups, n_cus)), dim3(512), 0, st, m);
     if ((rc = sskd::check_launch("fused_mlp_ln_kernel")) != SSKD_OK) return rc;
   }
   *final_hidden = x;

@@ -24,8 +24,10 @@ static float bf2float(unsigned short b) {
 }
 static float rbf(float f) { return bf2float(f2bf(f)); }
 
-int main() {
+int main(int argc, char** argv) {
   const int T = 131072;
+  const int grid = argc > 1 ? atoi(argv[1]) : 256;   // persistent workgroups (T / 128 = 1024: one group each, as before round 4)
+  printf("%d workgroups for %d groups of 128 tokens\n", grid, T / 128);
   srand(7);
   auto rnd = [](float s) { return s * ((rand() & 0xffff) / 32768.0f - 1.0f); };
   std::vector<float> W1((size_t)FF * H), W2((size_t)H * FF);
@@ -58,6 +60,7 @@ int main() {
     return d;
   };
   MlpParams m{};
+  m.n_groups = T / 128;
   m.x1 = (const bf16x8*)up(xh.data(), xh.size() * 2);
   m.w1 = (const bf16x8*)up(w1img.data(), w1img.size() * 2);
   m.w2p = (const bf16x8*)up(w2p.data(), w2p.size() * 2);
@@ -72,7 +75,7 @@ int main() {
   (void)hipEventCreate(&e1);
   for (int rep = 0; rep < 6; ++rep) {
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL(fused_mlp_ln_kernel<false>, dim3(T / 128), dim3(512), 0, 0, m);
+    hipLaunchKernelGGL(fused_mlp_ln_kernel<false>, dim3(grid), dim3(512), 0, 0, m);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms;
@@ -123,7 +126,7 @@ int main() {
     m.outp.eps = 1e-12f;
     for (int rep = 0; rep < 4; ++rep) {
       (void)hipEventRecord(e0);
-      hipLaunchKernelGGL(fused_mlp_ln_kernel<true>, dim3(T / 128), dim3(512), 0, 0, m);
+      hipLaunchKernelGGL(fused_mlp_ln_kernel<true>, dim3(grid), dim3(512), 0, 0, m);
       (void)hipEventRecord(e1);
       (void)hipEventSynchronize(e1);
       float ms;

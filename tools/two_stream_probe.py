@@ -1,12 +1,11 @@
-"""Same-process probe: 512 x 256 encode split into P parts over P HIP streams (library under test given
-by SSKD_LIB, default the in-tree one)."""
-import ctypes as C
-import os
+"""Experiment (round 4): does running the two halves of a 512 x 256 batch on two HIP streams, half a layer apart,
+overlap the fused MLP's un-hidden memory phases (its prologue / epilogue bursts) with the other half's compute?
+``python tools/two_stream_probe.py`` prints ms per 512-document forward: one stream, two streams in
+lockstep, two streams with the second one delayed by ~0.25 ms."""
 import sys
 import time
 from pathlib import Path
 
-import numpy as np
 import torch
 
 REPO = Path(__file__).resolve().parent.parent
@@ -18,35 +17,58 @@ from semantic_search_kd_amd.weights import BertConfig, DeviceWeights, synthetic_
 dev = torch.device("cuda:0")
 cfg = BertConfig()
 w = DeviceWeights(cfg, synthetic_state_dict(cfg), dev)
-ids, mask = synthetic_ids(512, 256, cfg.vocab_size, dev)
-out = torch.empty((512, 384), device=dev)
-main = torch.cuda.current_stream(dev)
-side = [torch.cuda.Stream(dev) for _ in range(7)]
-for path in sys.argv[1:]:
-    lib = C.CDLL(str(Path(path).resolve()))
-    for name in ("sskd_encoder_workspace_bytes", "sskd_encoder_forward"):
-        fn = getattr(lib, name)
-        fn.restype, fn.argtypes = _native.SIGNATURES[name]
-    for parts in (1, 2, 4, 8):
-        n = 512 // parts
-        wss = [torch.empty(int(lib.sskd_encoder_workspace_bytes(w.cstruct_cfg, n, 256)), dtype=torch.uint8, device=dev) for _ in range(parts)]
+lib = _native.load()
+B, S = 512, 256
+ids, mask = synthetic_ids(B, S, cfg.vocab_size, dev)
+out = torch.empty((B, 384), dtype=torch.float32, device=dev)
 
-        def run():
-            for p in range(1, parts):
-                side[p - 1].wait_stream(main)   # fork BEFORE anything of this step is enqueued on main
-            for p in range(parts):
-                st = main if p == 0 else side[p - 1]
-                rc = lib.sskd_encoder_forward(w.cstruct_cfg, w.struct, ids[p * n:].data_ptr(), mask[p * n:].data_ptr(), n, 256, 1,
-                                              out[p * n:].data_ptr(), wss[p].data_ptr(), wss[p].numel(), int(st.cuda_stream))
-                assert rc == 0
-            for p in range(1, parts):
-                main.wait_stream(side[p - 1])
 
-        for _ in range(3):
-            run()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(10):
-            run()
-        torch.cuda.synchronize()
-        print(f"{Path(path).stem}: {parts} stream(s) x {n} rows: {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms", flush=True)
+def ws_for(b):
+    return torch.empty(int(lib.sskd_encoder_workspace_bytes(w.cstruct_cfg, b, S)), dtype=torch.uint8, device=dev)
+
+
+ws_full, ws_a, ws_b = ws_for(B), ws_for(B // 2), ws_for(B // 2)
+s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+
+
+def fwd(lo, n, ws, stream):
+    rc = lib.sskd_encoder_forward(w.cstruct_cfg, w.struct, ids[lo:lo + n].data_ptr(), mask[lo:lo + n].data_ptr(), n, S, 1,
+                                  out[lo:lo + n].data_ptr(), ws.data_ptr(), ws.numel(), int(stream.cuda_stream))
+    assert rc == 0, rc
+
+
+def one_stream():
+    fwd(0, B, ws_full, s1)
+
+
+def two_streams(delay_cycles):
+    def go():
+        fwd(0, B // 2, ws_a, s1)
+        with torch.cuda.stream(s2):
+            if delay_cycles:
+                torch.cuda._sleep(delay_cycles)
+        fwd(B // 2, B // 2, ws_b, s2)
+    return go
+
+
+def timeit(f, n=20):
+    for _ in range(3):
+        f()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        f()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+one_stream()
+torch.cuda.synchronize()
+ref = out.clone()
+for name, f in (("one stream", one_stream), ("two streams, lockstep", two_streams(0)),
+                ("two streams, second delayed ~0.12 ms", two_streams(250_000)),
+                ("two streams, second delayed ~0.25 ms", two_streams(500_000)),
+                ("one stream", one_stream)):
+    ms = timeit(f)
+    torch.cuda.synchronize()
+    print(f"{name}: {ms:.3f} ms per 512 documents ({B / ms:.1f} k docs/s), max |diff| vs one stream {float((out - ref).abs().max()):.2e}", flush=True)
