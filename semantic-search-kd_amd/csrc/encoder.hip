@@ -578,9 +578,14 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
       // can land in its place while the consumers run their last burst and the LayerNorm
       if (FUSE_OUTPROJ && has_next)
         request_context_image(p.outp, (int64_t)(grp + (int)gridDim.x) * 4, ximg, hp, 4, lane);
-      __syncthreads();
-      __syncthreads();
-      __syncthreads();   // the consumers' LayerNorm statistics meet behind this barrier
+      // Bare barriers: __syncthreads() would make this wave wait for its DMA pieces (vmcnt(0): they write LDS) BEFORE it
+      // signals - and the consumers' last burst sits behind that barrier.  The producers' own LDS stores (h fragments)
+      // are what the first barrier publishes: lgkmcnt(0) alone.  The pieces are waited for in the next prologue.
+      // (Requesting the producers' residual rows and first Wo fragments here as well measured neutral: the consumers'
+      // half of those requests still opens the prologue.)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");   // the consumers' LayerNorm statistics meet behind this barrier
       SSKD_STAMP(0, 61, 0);
       if (!FUSE_OUTPROJ && has_next) __syncthreads();   // the consumers are done with the image before the next one is copied in
     }   // groups

@@ -174,6 +174,26 @@ def test_short_sequences_packed_per_workgroup(enc_l2, S):
     assert np.array_equal(alone[0], emb[5])
 
 
+def test_persistent_mlp_groups_match_one_group_per_workgroup(enc_l2):
+    """The fused MLP is a persistent kernel: one workgroup per CU walks the 128-token groups blockIdx, blockIdx + gridDim,
+    ... and its producers request the NEXT group's context rows while the consumers finish the current one
+    (csrc/encoder.hip fused_mlp_ln_kernel).  A 384 x 256 batch is 768 groups (three per workgroup on 256 CUs); the same rows
+    in slices of 64 are 128 groups (one per workgroup, nothing prefetched).  Rows are independent, so the two must agree
+    bit for bit - a context image that lands early or late shows up here."""
+    enc, cfg, sd = enc_l2
+    B, S = 384, 256
+    rng = np.random.default_rng(31)
+    lengths = [int(x) for x in rng.integers(2, S + 1, size=B)]
+    for b in range(0, B, 7):
+        lengths[b] = S
+    ids, mask = enc_oracle.synthetic_token_ids(B, S, seed=99, lengths=lengths)
+    whole = enc.encode_token_ids(ids, mask).cpu().numpy()
+    assert np.isfinite(whole).all()
+    for lo in range(0, B, 64):
+        part = enc.encode_token_ids(ids[lo:lo + 64], mask[lo:lo + 64]).cpu().numpy()
+        assert np.array_equal(part, whole[lo:lo + 64]), f"rows {lo}..{lo + 63}"
+
+
 def test_padding_invariance(enc_l2):
     """An embedding must not depend on batch-mates or on how far the row is padded."""
     enc, cfg, sd = enc_l2

@@ -337,3 +337,24 @@ def test_screened_search_launch_plan_is_sane_across_shapes():
     for n, nq, k in [(2047, 64, 10), (100_000, 63, 10), (100_000, 1000, 11), (100_000, 1000, 0)]:
         assert int(lib.sskd_index_search_screened_workspace_bytes(n, nq, k)) == 0
         assert lib.sskd_index_search_screened_plan(n, nq, k, None, None, None) != 0
+
+
+def test_w2_image_is_permuted_for_the_lane_local_hand_over():
+    """weights.tile_w2_chunked: slot j of lane l of fragment (chunk c, tile nt, k-step s2) must be
+    W2[32 nt + (l & 31)][32 c + 16 s2 + 8 (j >> 2) + 4 (l >> 5) + (j & 3)] - the order in which a producer lane's
+    accumulators (element 4g + e = hidden unit 8g + 4(l >> 5) + e) arrive, packed, as ITS OWN lane of the consumers' B
+    fragments (csrc/encoder.hip fused_mlp_ln_kernel, "Hand-over").  The W1 image keeps the plain A-fragment order."""
+    from semantic_search_kd_amd.weights import tile_w2_chunked, tile_weight_fragments
+
+    w2 = np.arange(384 * 1536, dtype=np.float32).reshape(384, 1536)
+    img = tile_w2_chunked(w2)
+    assert img.shape == (48, 12, 2, 64, 8)
+    c, nt, s2, l, j = np.meshgrid(np.arange(48), np.arange(12), np.arange(2), np.arange(64), np.arange(8), indexing="ij")
+    want = w2[32 * nt + (l & 31), 32 * c + 16 * s2 + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3)]
+    assert np.array_equal(img, want)
+    # every weight appears exactly once
+    assert np.array_equal(np.sort(img.ravel()), w2.ravel())
+    w1 = np.arange(1536 * 384, dtype=np.float32).reshape(1536, 384)
+    f = tile_weight_fragments(w1)
+    nt, s, l, j = np.meshgrid(np.arange(48), np.arange(24), np.arange(64), np.arange(8), indexing="ij")
+    assert np.array_equal(f, w1[32 * nt + (l & 31), 16 * s + 8 * (l >> 5) + j])
