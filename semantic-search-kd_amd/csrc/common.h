@@ -25,6 +25,52 @@ inline int check_launch(const char* what) {
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// compute units of the current device (256 on MI355X)
+int cu_count();
+
+// Side streams of the multi-branch forwards, per device, created on first use (process lifetime): index 0 .. 2.
+constexpr int MAX_STREAM_PARTS = 4;
+hipStream_t side_stream(int i);
+// Parts a batch is cut into by default (SSKD_FORWARD_STREAMS = 1 .. 4 for A/B runs; default 2).
+int forward_stream_parts();
+
+// Runs part(i, stream) for i = 0 .. parts - 1: part 0 on the caller's stream `st`, the others on side streams forked from
+// `st` and joined back into it with events (under stream capture the side streams join the capture and the graph gets
+// branches).  The joins are enqueued whatever a part returns, so a capturing caller always gets every branch back.
+// Returns the first error.  Why: every kernel of a part fills the chip by itself; what the branches buy is that the parts
+// drift apart, so that the un-overlapped memory phases of one (one workgroup per CU, every CU in the same phase) meet
+// the other's compute - measured + 4.8 % on the student encoder, + 2.7 % on the teacher.
+template <class F>
+int run_parts_on_streams(int parts, hipStream_t st, F&& part) {
+  if (parts > MAX_STREAM_PARTS) parts = MAX_STREAM_PARTS;
+  hipStream_t side[MAX_STREAM_PARTS - 1] = {};
+  for (int i = 0; i + 1 < parts; ++i)
+    if (!(side[i] = side_stream(i))) return fail(SSKD_ERR_HIP, "cannot create a side stream");
+  if (parts <= 1) return part(0, st);
+  hipEvent_t fork = nullptr, join[MAX_STREAM_PARTS - 1] = {};
+  bool ok = hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess;
+  for (int i = 0; ok && i + 1 < parts; ++i) ok = hipEventCreateWithFlags(&join[i], hipEventDisableTiming) == hipSuccess;
+  int rc = ok && hipEventRecord(fork, st) == hipSuccess ? SSKD_OK : fail(SSKD_ERR_HIP, "cannot fork the side streams");
+  int forked = 0;   // side streams that wait on the caller's stream (and, under capture, belong to its capture)
+  for (int i = 1; rc == SSKD_OK && i < parts; ++i) {
+    if (hipStreamWaitEvent(side[i - 1], fork, 0) != hipSuccess) {
+      rc = fail(SSKD_ERR_HIP, "cannot fork side stream %d", i);
+      break;
+    }
+    forked = i;
+    rc = part(i, side[i - 1]);
+  }
+  const int rc0 = rc == SSKD_OK ? part(0, st) : rc;
+  for (int i = 1; i <= forked; ++i)
+    if (!(hipEventRecord(join[i - 1], side[i - 1]) == hipSuccess && hipStreamWaitEvent(st, join[i - 1], 0) == hipSuccess) &&
+        rc == SSKD_OK)
+      rc = fail(SSKD_ERR_HIP, "cannot join side stream %d", i);
+  if (fork) (void)hipEventDestroy(fork);   // destruction is deferred until the recorded work has completed
+  for (hipEvent_t e : join)
+    if (e) (void)hipEventDestroy(e);
+  return rc != SSKD_OK ? rc : rc0;
+}
+
 }  // namespace sskd
 
 #define SSKD_REQUIRE(cond, ...) \

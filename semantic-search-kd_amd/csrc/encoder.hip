@@ -1354,25 +1354,13 @@ int check_cfg(const sskd_encoder_config* cfg, const sskd_encoder_weights* w, int
   return SSKD_OK;
 }
 
-// compute units of the current device (the persistent fused MLP launches one workgroup per CU)
-int cu_count() {
-  static int cached[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-  if (cached[dev] == 0) {
-    int n = 0;
-    cached[dev] = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0 ? n : 256;
-  }
-  return cached[dev];
-}
-
 // runs embeddings + all layers; returns the (fragment-order) buffer holding the final hidden states
 int run_layers(const sskd_encoder_config* cfg, const sskd_encoder_weights* w, const int32_t* d_ids,
                const int32_t* d_mask, int B, int S, const Workspace& ws, hipStream_t st,
                __bf16** final_hidden, const int32_t* d_seg = nullptr) {
   const int Sp = s_pad_of(S), nkt = Sp / 32;
   const int Tpad = (int)t_pad_of(B, S);
-  const int n_cus = cu_count();
+  const int n_cus = sskd::cu_count();   // the persistent fused MLP launches one workgroup per CU
   hipLaunchKernelGGL(embed_ln_kernel, dim3(Tpad / 32), dim3(256), 0, st, d_ids,
                      static_cast<const bf16x8*>(w->word_emb), static_cast<const bf16x8*>(w->pos_emb),
                      static_cast<const bf16x8*>(w->type_emb), w->emb_ln_g, w->emb_ln_b, B, S, Sp,
@@ -1507,30 +1495,9 @@ int forward_rows(const sskd_encoder_config* cfg, const sskd_encoder_weights* w, 
   return sskd::check_launch("pool_normalize_frag_kernel");
 }
 
-// the side streams of the split forward, per device, created on first use (never destroyed: process lifetime)
-constexpr int MAX_PARTS = 4;
-hipStream_t side_stream(int i) {
-  static std::mutex mu;
-  static hipStream_t streams[64][MAX_PARTS - 1] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || i < 0 || i >= MAX_PARTS - 1) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  if (!streams[dev][i] && hipStreamCreateWithFlags(&streams[dev][i], hipStreamNonBlocking) != hipSuccess)
-    streams[dev][i] = nullptr;
-  return streams[dev][i];
-}
-
-int split_forward_parts() {   // SSKD_ENCODER_STREAMS=1 .. 4 (A/B runs); default 2
-  static const int n = [] {
-    const char* e = std::getenv("SSKD_ENCODER_STREAMS");
-    const int v = e ? std::atoi(e) : 2;
-    return v < 1 ? 1 : (v > MAX_PARTS ? MAX_PARTS : v);
-  }();
-  return n;
-}
 }  // namespace
 
-// Large batches run as TWO (SSKD_ENCODER_STREAMS: 1 .. 4) parts on as many streams (the caller's and side streams forked
+// Large batches run as TWO (SSKD_FORWARD_STREAMS: 1 .. 4) parts on as many streams (the caller's and side streams forked
 // from / joined back into it with events; under stream capture the side streams join the capture, the graph gets
 // branches).  Every kernel of a part fills the chip by itself; what the branches buy is that the parts drift apart: the fused MLP's memory bursts at
 // both ends of every 128-token group (one workgroup per CU, nothing else resident) then meet the other half's attention
@@ -1546,51 +1513,19 @@ int sskd_encoder_forward(const sskd_encoder_config* cfg, const sskd_encoder_weig
   hipStream_t st = sskd::as_stream(stream);
   // every part must fill the chip twice over (>= 2 groups of 128 tokens per CU: the measured configuration; four parts of one
   // round each measured +1.5 % where two parts gave +4.8 %) and start on a 256-row boundary
-  int parts = split_forward_parts();
+  int parts = sskd::forward_stream_parts();
   while (parts > 1 && !(B % parts == 0 && ((int64_t)(B / parts) * s_pad_of(S)) % 256 == 0 &&
-                        (int64_t)(B / parts) * s_pad_of(S) / 128 >= 2 * cu_count()))
+                        (int64_t)(B / parts) * s_pad_of(S) / 128 >= 2 * sskd::cu_count()))
     --parts;
-  hipStream_t side[MAX_PARTS - 1] = {};
-  for (int i = 0; i + 1 < parts; ++i)
-    if (!(side[i] = side_stream(i))) parts = 1;
-  if (parts == 1) return forward_rows(cfg, w, d_ids, d_mask, B, S, normalize, d_out, ws, st);
-
   const int Bp = B / parts;
   const int64_t Tp = (int64_t)Bp * s_pad_of(S);   // rows of one part in the token buffers
-  hipEvent_t fork = nullptr, join[MAX_PARTS - 1] = {};
-  bool ok = hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess;
-  for (int i = 0; ok && i + 1 < parts; ++i) ok = hipEventCreateWithFlags(&join[i], hipEventDisableTiming) == hipSuccess;
-  auto drop_events = [&] {   // destruction is deferred until the recorded work has completed
-    if (fork) (void)hipEventDestroy(fork);
-    for (hipEvent_t e : join)
-      if (e) (void)hipEventDestroy(e);
-  };
-  if (!ok) {
-    drop_events();
-    return forward_rows(cfg, w, d_ids, d_mask, B, S, normalize, d_out, ws, st);
-  }
-  rc = hipEventRecord(fork, st) == hipSuccess ? SSKD_OK : sskd::fail(SSKD_ERR_HIP, "encoder_forward: cannot fork");
-  int forked = 0;   // side streams that joined the caller's stream (and, under capture, its capture)
-  for (int i = 1; rc == SSKD_OK && i < parts; ++i) {
-    if (hipStreamWaitEvent(side[i - 1], fork, 0) != hipSuccess) {
-      rc = sskd::fail(SSKD_ERR_HIP, "encoder_forward: cannot fork the side stream");
-      break;
-    }
-    forked = i;
+  return sskd::run_parts_on_streams(parts, st, [&](int i, hipStream_t s) {
     Workspace wp = ws;
     wp.xa = ws.xa + i * Tp * H;
     wp.ctx = ws.ctx + i * Tp * H;
-    rc = forward_rows(cfg, w, d_ids + (int64_t)i * Bp * S, d_mask + (int64_t)i * Bp * S, Bp, S, normalize,
-                      d_out + (int64_t)i * Bp * H, wp, side[i - 1]);
-  }
-  const int rc0 = rc == SSKD_OK ? forward_rows(cfg, w, d_ids, d_mask, Bp, S, normalize, d_out, ws, st) : rc;
-  // the joins are enqueued whatever happened: a capturing caller must get every branch back
-  for (int i = 1; i <= forked; ++i)
-    if (!(hipEventRecord(join[i - 1], side[i - 1]) == hipSuccess && hipStreamWaitEvent(st, join[i - 1], 0) == hipSuccess) &&
-        rc == SSKD_OK)
-      rc = sskd::fail(SSKD_ERR_HIP, "encoder_forward: cannot join the side stream");
-  drop_events();
-  return rc != SSKD_OK ? rc : rc0;
+    return forward_rows(cfg, w, d_ids + (int64_t)i * Bp * S, d_mask + (int64_t)i * Bp * S, Bp, S, normalize,
+                        d_out + (int64_t)i * Bp * H, wp, s);
+  });
 }
 
 

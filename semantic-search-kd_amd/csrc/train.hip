@@ -618,26 +618,57 @@ size_t sskd_teacher_workspace_bytes(const sskd_generic_config* cfg, int B, int S
 
 // Cross-encoder score: generic encoder -> hidden state of token 0 (<s>) -> dense + tanh -> out_proj
 // (XLMRobertaForSequenceClassification's RobertaClassificationHead with num_labels = 1); the head runs in fp32.
-int sskd_teacher_score(const sskd_generic_config* cfg, const sskd_generic_weights* w, const float* d_head_dense_w,
-                       const float* d_head_dense_b, const float* d_head_out_w, const float* d_head_out_b,
-                       const int32_t* d_ids, const int32_t* d_mask, int B, int S, float* d_logits, void* d_workspace,
-                       size_t workspace_bytes, void* stream) {
+static int teacher_score_rows(const sskd_generic_config* cfg, const sskd_generic_weights* w, const float* d_head_dense_w,
+                              const float* d_head_dense_b, const float* d_head_out_w, const float* d_head_out_b,
+                              const int32_t* d_ids, const int32_t* d_mask, int B, int S, float* d_logits, void* d_workspace,
+                              size_t workspace_bytes, hipStream_t st) {
   Dims d{};
   std::vector<LayerSaved> layers;
   Saved sv{};
-  const size_t need = cfg ? sskd_teacher_workspace_bytes(cfg, B, S) : 0;
-  if (B > 0 && (!d_workspace || workspace_bytes < need))
+  const size_t need = sskd_teacher_workspace_bytes(cfg, B, S);
+  if (!d_workspace || workspace_bytes < need)
     return sskd::fail(SSKD_ERR_WORKSPACE, "teacher_score: workspace %zu B < required %zu B", workspace_bytes, need);
   int rc = prepare(cfg, w, B, S, 0, d_workspace, need, &d, &layers, &sv);
-  if (rc != SSKD_OK || B == 0) return rc;
-  SSKD_REQUIRE(d_head_dense_w && d_head_dense_b && d_head_out_w && d_head_out_b && d_ids && d_mask && d_logits,
-               "teacher_score: null pointer");
-  hipStream_t st = sskd::as_stream(stream);
+  if (rc != SSKD_OK) return rc;
   const bf16_t* fin = nullptr;
   TRY(forward_all(cfg, w, d, d_ids, d_mask, sv, st, &fin));
   hipLaunchKernelGGL(teacher_head_kernel, dim3(B), dim3(HEAD_WAVES * 64), 0, st, fin, S, d.H, d_head_dense_w, d_head_dense_b,
                      d_head_out_w, d_head_out_b, d_logits);
   return sskd::check_launch("teacher_head_kernel");
+}
+
+// Batches of >= 2 x 16 384 tokens run as two halves on two streams (sskd::run_parts_on_streams: + 2.7 % at 128 pairs x 256
+// tokens, tools/two_stream_teacher_probe.py; a pair's score does not depend on its batch-mates: bit-identical).  Each half
+// must keep its token count a multiple of 256 (the 256-row GEMM tiles) and carve its own workspace out of the caller's.
+int sskd_teacher_score(const sskd_generic_config* cfg, const sskd_generic_weights* w, const float* d_head_dense_w,
+                       const float* d_head_dense_b, const float* d_head_out_w, const float* d_head_out_b,
+                       const int32_t* d_ids, const int32_t* d_mask, int B, int S, float* d_logits, void* d_workspace,
+                       size_t workspace_bytes, void* stream) {
+  {   // argument checks that do not depend on the split (prepare validates cfg / w / shapes)
+    Dims d{};
+    std::vector<LayerSaved> layers;
+    Saved sv{};
+    const size_t need = cfg ? sskd_teacher_workspace_bytes(cfg, B, S) : 0;
+    if (B > 0 && (!d_workspace || workspace_bytes < need))
+      return sskd::fail(SSKD_ERR_WORKSPACE, "teacher_score: workspace %zu B < required %zu B", workspace_bytes, need);
+    int rc = prepare(cfg, w, B, S, 0, d_workspace, need, &d, &layers, &sv);
+    if (rc != SSKD_OK || B == 0) return rc;
+  }
+  SSKD_REQUIRE(d_head_dense_w && d_head_dense_b && d_head_out_w && d_head_out_b && d_ids && d_mask && d_logits,
+               "teacher_score: null pointer");
+  hipStream_t st = sskd::as_stream(stream);
+  int parts = sskd::forward_stream_parts() >= 2 ? 2 : 1;
+  const int Bp = B / 2;
+  const size_t part_bytes = (sskd_teacher_workspace_bytes(cfg, Bp, S) + 255) & ~(size_t)255;
+  if (!(B % 2 == 0 && ((int64_t)Bp * S) % 256 == 0 && (int64_t)Bp * S >= 16384 && 2 * part_bytes <= workspace_bytes)) parts = 1;
+  if (parts == 1)
+    return teacher_score_rows(cfg, w, d_head_dense_w, d_head_dense_b, d_head_out_w, d_head_out_b, d_ids, d_mask, B, S,
+                              d_logits, d_workspace, workspace_bytes, st);
+  return sskd::run_parts_on_streams(2, st, [&](int i, hipStream_t s) {
+    return teacher_score_rows(cfg, w, d_head_dense_w, d_head_dense_b, d_head_out_w, d_head_out_b,
+                              d_ids + (int64_t)i * Bp * S, d_mask + (int64_t)i * Bp * S, Bp, S, d_logits + (int64_t)i * Bp,
+                              static_cast<char*>(d_workspace) + i * part_bytes, part_bytes, s);
+  });
 }
 
 // test hook: the NT GEMM by itself
