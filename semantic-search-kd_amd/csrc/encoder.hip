@@ -1596,9 +1596,24 @@ int sskd_encoder_forward_packed(const sskd_encoder_config* cfg, const sskd_encod
   if (rc != SSKD_OK || n_rows == 0 || n_seq == 0) return rc;
   SSKD_REQUIRE(n_seq > 0 && d_ids && d_seg && d_table && d_out, "encoder_forward_packed: null pointer");
   hipStream_t st = sskd::as_stream(stream);
-  __bf16* fin = nullptr;
-  rc = run_layers(cfg, w, d_ids, nullptr, n_rows, capacity, ws, st, &fin, d_seg);
+  // the layers in two branches like sskd_encoder_forward (packed rows do not interact either); the pooling reads rows of
+  // both parts and runs behind the join
+  int parts = sskd::forward_stream_parts();
+  while (parts > 1 && !(n_rows % parts == 0 && ((int64_t)(n_rows / parts) * capacity) % 256 == 0 &&
+                        (int64_t)(n_rows / parts) * capacity / 128 >= 2 * sskd::cu_count()))
+    --parts;
+  const int Rp = n_rows / parts;
+  const int64_t Tp = (int64_t)Rp * capacity;
+  __bf16* fins[sskd::MAX_STREAM_PARTS] = {};
+  rc = sskd::run_parts_on_streams(parts, st, [&](int i, hipStream_t s) {
+    Workspace wp = ws;
+    wp.xa = ws.xa + i * Tp * H;
+    wp.ctx = ws.ctx + i * Tp * H;
+    return run_layers(cfg, w, d_ids + (int64_t)i * Rp * capacity, nullptr, Rp, capacity, wp, s, &fins[i],
+                      d_seg + (int64_t)i * Rp * capacity);
+  });
   if (rc != SSKD_OK) return rc;
+  __bf16* fin = fins[0];   // the parts' final buffers are consecutive slices of one buffer
   hipLaunchKernelGGL(pool_normalize_packed_kernel, dim3(n_seq), dim3(512), 0, st,
                      reinterpret_cast<const bf16x8*>(fin), reinterpret_cast<const int4*>(d_table),
                      capacity / 32, normalize, d_out);
