@@ -275,7 +275,12 @@ typedef struct sskd_encoder_weights {
 size_t sskd_encoder_workspace_bytes(const sskd_encoder_config* cfg, int B, int S);
 
 /* Full forward: ids/mask int32 [B, S] -> L2-normalised (if normalize) fp32 [B, 384].
- * bf16 activations and MFMA operands, fp32 accumulation / LayerNorm / softmax. */
+ * bf16 activations and MFMA operands, fp32 accumulation / LayerNorm / softmax.
+ * Stream semantics: everything is ordered after the work already in `stream` and complete for work enqueued on it
+ * afterwards.  Batches whose halves still fill the chip twice (>= 2 x 65 536 padded tokens) run as two halves, one of
+ * them on an internal side stream forked from and joined back into `stream` with events (legal under stream capture: the
+ * graph gets two branches); the result is bit-identical, rows do not interact.  SSKD_FORWARD_STREAMS=1 in the environment
+ * keeps every forward of the library (this one, the packed one, sskd_teacher_score) on the caller's stream alone. */
 int sskd_encoder_forward(const sskd_encoder_config* cfg, const sskd_encoder_weights* w,
                          const int32_t* d_ids, const int32_t* d_mask, int B, int S,
                          int normalize, float* d_out, void* d_workspace,
