@@ -324,3 +324,37 @@ def test_captured_forward_replays_the_eager_forward(gpu):
     enc.weights = DeviceWeights(cfg, enc._host_state, enc.device)      # e.g. after a training step re-tiled them
     with pytest.raises(RuntimeError, match="weights changed"):
         fwd.replay()
+
+
+@pytest.mark.gpu
+def test_two_branch_forward_matches_slices_eager_and_captured(gpu):
+    """sskd_encoder_forward runs a batch whose halves each hold >= 2 groups of 128 tokens per CU (512 x 256 on 256 CUs) as
+    TWO halves, one on a side stream forked from / joined back into the caller's stream (csrc/common.h
+    run_parts_on_streams).  Rows do not interact, so the whole batch must equal the same rows in slices of 64 (one stream,
+    one group per workgroup) bit for bit - eagerly, and replayed as one captured HIP graph (the side stream joins the
+    capture; refilled inputs are followed)."""
+    from semantic_search_kd_amd.bench_support import synthetic_ids
+
+    cfg = BertConfig(num_hidden_layers=2)
+    enc = Mi355xSentenceEncoder.from_synthetic(cfg, device="cuda:0")
+    dev = torch.device("cuda:0")
+    B, S = 512, 256
+    ids, mask = synthetic_ids(B, S, cfg.vocab_size, dev, seed=11)
+    mask[5, 40:] = 0          # a few ragged rows in both halves
+    mask[300, 7:] = 0
+    mask[511, 200:] = 0
+
+    def in_slices(i, m):
+        return torch.cat([enc.encode_token_ids(i[lo:lo + 64], m[lo:lo + 64]).clone() for lo in range(0, B, 64)])
+
+    want = in_slices(ids, mask)
+    got = enc.encode_token_ids(ids, mask).clone()
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, want)
+    fwd = enc.capture_forward(ids, mask)
+    assert torch.equal(fwd.replay(), want)
+    ids2, mask2 = synthetic_ids(B, S, cfg.vocab_size, dev, seed=12)
+    want2 = in_slices(ids2, mask2)
+    ids.copy_(ids2)
+    mask.copy_(mask2)
+    assert torch.equal(fwd.replay(), want2) and not torch.equal(want, want2)

@@ -346,3 +346,29 @@ def test_teacher_data_parallel_two_ranks_and_teacher_miner(gpu, tmp_path):
     assert np.array_equal(got[0]["kept"], got[1]["kept"])
     if np.array_equal(got[0]["scores"], want):
         assert list(got[0]["ids"]) == [",".join(x) for x in ids]
+
+
+@pytest.mark.gpu
+def test_teacher_two_branch_batch_equals_its_halves(gpu):
+    """sskd_teacher_score runs batches of >= 2 x 16 384 tokens as two halves on two streams (csrc/train.hip, one of them a
+    side stream forked from / joined into the caller's).  A pair's score does not depend on its batch-mates: 128 pairs x
+    256 tokens must equal the two 64-pair calls (each below the split threshold: one stream) bit for bit."""
+    from semantic_search_kd_amd import TeacherModel
+    from semantic_search_kd_amd.teacher import TeacherConfig, synthetic_teacher_state_dict
+
+    cfg = TeacherConfig(vocab_size=800, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512,
+                        max_position_embeddings=260)
+    teacher = TeacherModel("synthetic", "cuda:0", config=cfg, state_dict=synthetic_teacher_state_dict(cfg))
+    rng = np.random.default_rng(3)
+    P, S = 128, 256
+    ids = rng.integers(4, cfg.vocab_size, size=(P, S)).astype(np.int32)
+    ids[:, 0] = 0
+    mask = np.ones((P, S), np.int32)
+    for b in (1, 40, 64, 127):
+        n = int(rng.integers(3, S))
+        mask[b, n:] = 0
+        ids[b, n:] = cfg.pad_token_id
+    whole = teacher.score_token_ids(ids, mask).cpu().numpy()
+    assert np.isfinite(whole).all()
+    halves = np.concatenate([teacher.score_token_ids(ids[lo:lo + 64], mask[lo:lo + 64]).cpu().numpy() for lo in (0, 64)])
+    assert np.array_equal(whole, halves)
