@@ -67,23 +67,7 @@ __device__ inline bf16x8 zero_bf8() {
 
 __device__ inline float bf2f(__bf16 v) { return (float)v; }
 
-// erf-GELU (HF "gelu") = x Phi(x), evaluated as x * sigmoid(x (a + b x^2 + c x^4)) with (a, b, c)
-// fitted (minimax on [-8, 8]) to the exact erf form: max |error| 2.6e-5 - the same bound as the
-// Abramowitz-Stegun 7.1.25 erf it replaces, 80x below the bf16 half-ulp of the value produced -
-// in 7 VALU + 2 transcendental instructions instead of 10 + 2 (the MLP is bound by the SIMD's
-// instruction issue, not by the matrix pipe: every VALU instruction per element is 16 x 4 issue
-// cycles per chunk).  The polynomial is evaluated on clamp(x, -8, 8) (beyond, sigmoid is 0 or 1 to
-// fp32 precision and the quartic term would turn over at |x| > 11); coefficients carry the
-// -log2(e) of exp(-t) = exp2(-t log2 e).
-__device__ inline float gelu_erf(float x) {
-  constexpr float A = -2.3011212f, B = -0.10677574f, C = 0.0010142655f;
-  const float xc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);
-  const float x2 = xc * xc;
-  float q = fmaf(C, x2, B);
-  q = fmaf(q, x2, A);
-  const float e = __builtin_amdgcn_exp2f(q * xc);
-  return x * __builtin_amdgcn_rcpf(1.0f + e);
-}
+using sskd::gelu_erf;   // common.h: erf-GELU as x * sigmoid(cubic-in-x^2), 7 VALU + 2 transcendental instructions
 
 // Exchange with lane ^ 32 in the VALU (v_permlane32_swap) instead of __shfl_xor's ds_bpermute,
 // which is an LDS round trip in the middle of a dependency chain.  After the swap r[0] / r[1]

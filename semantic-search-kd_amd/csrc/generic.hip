@@ -10,6 +10,16 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
+// erf-GELU of the GEMM epilogues (inference: the teacher's FFN1).  sskd::gelu_erf (common.h): x * sigmoid(cubic in x^2),
+// |error| <= 2.6e-5 - 80 x below the bf16 half-ulp of the value produced - in 9 instructions; libm's erff is ~40, all of it
+// un-overlapped vector time (128 values per lane and tile while the matrix pipe idles).  -DSSKD_GELU_LIBM: the old form (A/B).
+__device__ inline float epilogue_gelu(float x) {
+#ifdef SSKD_GELU_LIBM
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+#else
+  return sskd::gelu_erf(x);
+#endif
+}
 
 __device__ inline float wave_sum(float v) {
 #pragma unroll
@@ -125,7 +135,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
           for (int e = 0; e < 4; ++e)
           {
             float v = p.alpha * acc[i][j][4 * g + e] + bias;
-            if (p.act == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+            if (p.act == 1) v = epilogue_gelu(v);
             Ct[(wm * 64 + i * 32 + 8 * g + 4 * h + e) * LDC + nl] = (bf16_t)v;
           }
       }
@@ -340,7 +350,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float x = p.alpha * acc[i][j][e] + bias4[j][e];
-          if (p.act == 1) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+          if (p.act == 1) x = epilogue_gelu(x);
           o[e] = (bf16_t)x;
         }
         *reinterpret_cast<bf16x4*>(wt + fr * LDW + j * 16 + 4 * fq) = o;
