@@ -537,12 +537,40 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void teacher_head_kernel(const bf1
 
 extern "C" {
 
-size_t sskd_generic_workspace_bytes(const sskd_generic_config* cfg, int B, int S, int training) {
+static size_t workspace_one_part(const sskd_generic_config* cfg, int B, int S, int training) {
   Dims d{};
   sskd_generic_weights dummy{};
   if (!cfg || B <= 0 || check(cfg, &dummy, B, S, &d) != SSKD_OK) return 0;
   std::vector<LayerSaved> tmp((size_t)(d.L > 0 ? d.L : 1));
   return carve(nullptr, d, tmp.data(), training != 0).bytes;
+}
+
+// Batches of >= 2 x 16 384 tokens run as TWO halves on two streams (sskd::run_parts_on_streams: a side stream forked from /
+// joined into the caller's; rows do not interact).  The rule depends on (cfg, B, S, training) alone, so the forward that
+// saves activations and the backward that reads them cut the batch - and the workspace - the same way.  Each half keeps
+// its token count a multiple of 256 (the 256-row GEMM tiles).  Training splits only where every weight gradient goes
+// through the atomically accumulating product (gemm_tn_supported): the halves add into the same gradient buffers.
+static int generic_parts(const sskd_generic_config* cfg, int B, int S, int training) {
+  if (sskd::forward_stream_parts() < 2 || !cfg || B < 2 || B % 2 != 0) return 1;
+  const int64_t T = (int64_t)(B / 2) * S;
+  if (T % 256 != 0 || T < 16384) return 1;
+  if (training) {
+    const int H = cfg->hidden, F = cfg->intermediate;
+    if (!(gemm_tn_supported(T, 3 * H, H, 3 * H, H) && gemm_tn_supported(T, H, H, H, H) && gemm_tn_supported(T, F, H, F, H) &&
+          gemm_tn_supported(T, H, F, H, F)))
+      return 1;
+  }
+  return 2;
+}
+static size_t part_stride(const sskd_generic_config* cfg, int B, int S, int training) {   // bytes between the halves
+  return (workspace_one_part(cfg, B / 2, S, training) + 255) & ~(size_t)255;
+}
+
+size_t sskd_generic_workspace_bytes(const sskd_generic_config* cfg, int B, int S, int training) {
+  const size_t whole = workspace_one_part(cfg, B, S, training);
+  if (whole == 0 || generic_parts(cfg, B, S, training) == 1) return whole;
+  const size_t split = 2 * part_stride(cfg, B, S, training);
+  return split > whole ? split : whole;
 }
 
 static int prepare(const sskd_generic_config* cfg, const sskd_generic_weights* w, int B, int S, int training,
@@ -553,7 +581,7 @@ static int prepare(const sskd_generic_config* cfg, const sskd_generic_weights* w
   SSKD_REQUIRE(w->word_emb && w->pos_emb && w->type_emb && w->emb_ln_g && w->emb_ln_b && (cfg->layers == 0 || w->layers),
                "generic encoder: null weight pointer");
   if (B == 0) return SSKD_OK;
-  const size_t need = sskd_generic_workspace_bytes(cfg, B, S, training);
+  const size_t need = workspace_one_part(cfg, B, S, training);
   if (!d_workspace || workspace_bytes < need)
     return sskd::fail(SSKD_ERR_WORKSPACE, "generic encoder: workspace %zu B < required %zu B", workspace_bytes, need);
   layers->resize((size_t)(d->L > 0 ? d->L : 1));
@@ -561,16 +589,14 @@ static int prepare(const sskd_generic_config* cfg, const sskd_generic_weights* w
   return SSKD_OK;
 }
 
-int sskd_generic_forward(const sskd_generic_config* cfg, const sskd_generic_weights* w, const int32_t* d_ids,
-                         const int32_t* d_mask, int B, int S, int training, int pool, int normalize, void* d_out,
-                         void* d_workspace, size_t workspace_bytes, void* stream) {
+static int generic_forward_rows(const sskd_generic_config* cfg, const sskd_generic_weights* w, const int32_t* d_ids,
+                                const int32_t* d_mask, int B, int S, int training, int pool, int normalize, void* d_out,
+                                void* d_workspace, size_t workspace_bytes, hipStream_t st) {
   Dims d{};
   std::vector<LayerSaved> layers;
   Saved sv{};
   int rc = prepare(cfg, w, B, S, training, d_workspace, workspace_bytes, &d, &layers, &sv);
   if (rc != SSKD_OK || B == 0) return rc;
-  SSKD_REQUIRE(d_ids && d_mask && d_out, "generic_forward: null pointer");
-  hipStream_t st = sskd::as_stream(stream);
   const bf16_t* fin = nullptr;
   TRY(forward_all(cfg, w, d, d_ids, d_mask, sv, st, &fin));
   if (pool) return launch_pool_fwd(fin, d_mask, B, S, d.H, normalize, static_cast<float*>(d_out), sv.pooled, st);
@@ -580,9 +606,35 @@ int sskd_generic_forward(const sskd_generic_config* cfg, const sskd_generic_weig
   return SSKD_OK;
 }
 
-int sskd_generic_backward(const sskd_generic_config* cfg, const sskd_generic_weights* w, const sskd_generic_grads* grads,
-                          const int32_t* d_ids, const int32_t* d_mask, int B, int S, int normalize, const float* d_dout,
-                          void* d_workspace, size_t workspace_bytes, void* stream) {
+int sskd_generic_forward(const sskd_generic_config* cfg, const sskd_generic_weights* w, const int32_t* d_ids,
+                         const int32_t* d_mask, int B, int S, int training, int pool, int normalize, void* d_out,
+                         void* d_workspace, size_t workspace_bytes, void* stream) {
+  {   // validation of the whole call (and its workspace) before anything is enqueued
+    Dims d{};
+    int rc = check(cfg, w, B, S, &d);
+    if (rc != SSKD_OK || B == 0) return rc;
+    const size_t need = sskd_generic_workspace_bytes(cfg, B, S, training);
+    if (!d_workspace || workspace_bytes < need)
+      return sskd::fail(SSKD_ERR_WORKSPACE, "generic encoder: workspace %zu B < required %zu B", workspace_bytes, need);
+  }
+  SSKD_REQUIRE(d_ids && d_mask && d_out, "generic_forward: null pointer");
+  hipStream_t st = sskd::as_stream(stream);
+  const int parts = generic_parts(cfg, B, S, training);
+  if (parts == 1)
+    return generic_forward_rows(cfg, w, d_ids, d_mask, B, S, training, pool, normalize, d_out, d_workspace, workspace_bytes, st);
+  const int Bp = B / 2;
+  const size_t stride = part_stride(cfg, B, S, training);
+  const size_t out_row = pool ? (size_t)cfg->hidden * sizeof(float) : (size_t)S * cfg->hidden * sizeof(bf16_t);
+  return sskd::run_parts_on_streams(2, st, [&](int i, hipStream_t s) {
+    return generic_forward_rows(cfg, w, d_ids + (int64_t)i * Bp * S, d_mask + (int64_t)i * Bp * S, Bp, S, training, pool,
+                                normalize, static_cast<char*>(d_out) + (size_t)i * Bp * out_row,
+                                static_cast<char*>(d_workspace) + i * stride, stride, s);
+  });
+}
+
+static int generic_backward_rows(const sskd_generic_config* cfg, const sskd_generic_weights* w, const sskd_generic_grads* grads,
+                                 const int32_t* d_ids, const int32_t* d_mask, int B, int S, int normalize, const float* d_dout,
+                                 void* d_workspace, size_t workspace_bytes, hipStream_t st) {
   Dims d{};
   std::vector<LayerSaved> layers;
   Saved sv{};
@@ -592,7 +644,6 @@ int sskd_generic_backward(const sskd_generic_config* cfg, const sskd_generic_wei
   SSKD_REQUIRE(grads->word_emb && grads->pos_emb && grads->type_emb && grads->emb_ln_g && grads->emb_ln_b &&
                    (cfg->layers == 0 || grads->layers),
                "generic_backward: null gradient pointer");
-  hipStream_t st = sskd::as_stream(stream);
   // gradient flowing into the current layer's output = dx + dxb (dxb: the residual share, null at the top)
   const bf16_t* dx = sv.tH2;
   const bf16_t* dxb = nullptr;
@@ -612,6 +663,30 @@ int sskd_generic_backward(const sskd_generic_config* cfg, const sskd_generic_wei
                           grads->pos_emb, grads->type_emb, st);
 }
 
+int sskd_generic_backward(const sskd_generic_config* cfg, const sskd_generic_weights* w, const sskd_generic_grads* grads,
+                          const int32_t* d_ids, const int32_t* d_mask, int B, int S, int normalize, const float* d_dout,
+                          void* d_workspace, size_t workspace_bytes, void* stream) {
+  {
+    Dims d{};
+    int rc = check(cfg, w, B, S, &d);
+    if (rc != SSKD_OK || B == 0) return rc;
+    const size_t need = sskd_generic_workspace_bytes(cfg, B, S, 1);
+    if (!d_workspace || workspace_bytes < need)
+      return sskd::fail(SSKD_ERR_WORKSPACE, "generic encoder: workspace %zu B < required %zu B", workspace_bytes, need);
+  }
+  hipStream_t st = sskd::as_stream(stream);
+  const int parts = generic_parts(cfg, B, S, 1);
+  if (parts == 1)
+    return generic_backward_rows(cfg, w, grads, d_ids, d_mask, B, S, normalize, d_dout, d_workspace, workspace_bytes, st);
+  // the halves ADD into the same gradient buffers: every accumulation of the backward is atomic (generic_parts)
+  const int Bp = B / 2;
+  const size_t stride = part_stride(cfg, B, S, 1);
+  return sskd::run_parts_on_streams(2, st, [&](int i, hipStream_t s) {
+    return generic_backward_rows(cfg, w, grads, d_ids + (int64_t)i * Bp * S, d_mask + (int64_t)i * Bp * S, Bp, S, normalize,
+                                 d_dout + (int64_t)i * Bp * cfg->hidden, static_cast<char*>(d_workspace) + i * stride, stride, s);
+  });
+}
+
 size_t sskd_teacher_workspace_bytes(const sskd_generic_config* cfg, int B, int S) {
   return sskd_generic_workspace_bytes(cfg, B, S, 0);
 }
@@ -625,10 +700,7 @@ static int teacher_score_rows(const sskd_generic_config* cfg, const sskd_generic
   Dims d{};
   std::vector<LayerSaved> layers;
   Saved sv{};
-  const size_t need = sskd_teacher_workspace_bytes(cfg, B, S);
-  if (!d_workspace || workspace_bytes < need)
-    return sskd::fail(SSKD_ERR_WORKSPACE, "teacher_score: workspace %zu B < required %zu B", workspace_bytes, need);
-  int rc = prepare(cfg, w, B, S, 0, d_workspace, need, &d, &layers, &sv);
+  int rc = prepare(cfg, w, B, S, 0, d_workspace, workspace_bytes, &d, &layers, &sv);
   if (rc != SSKD_OK) return rc;
   const bf16_t* fin = nullptr;
   TRY(forward_all(cfg, w, d, d_ids, d_mask, sv, st, &fin));
@@ -637,30 +709,26 @@ static int teacher_score_rows(const sskd_generic_config* cfg, const sskd_generic
   return sskd::check_launch("teacher_head_kernel");
 }
 
-// Batches of >= 2 x 16 384 tokens run as two halves on two streams (sskd::run_parts_on_streams: + 2.7 % at 128 pairs x 256
-// tokens, tools/two_stream_teacher_probe.py; a pair's score does not depend on its batch-mates: bit-identical).  Each half
-// must keep its token count a multiple of 256 (the 256-row GEMM tiles) and carve its own workspace out of the caller's.
+// Batches of >= 2 x 16 384 tokens run as two halves on two streams (generic_parts above: + 1.5 ... 2.7 % at 128 pairs x 256
+// tokens, tools/two_stream_teacher_probe.py; a pair's score does not depend on its batch-mates: bit-identical).
 int sskd_teacher_score(const sskd_generic_config* cfg, const sskd_generic_weights* w, const float* d_head_dense_w,
                        const float* d_head_dense_b, const float* d_head_out_w, const float* d_head_out_b,
                        const int32_t* d_ids, const int32_t* d_mask, int B, int S, float* d_logits, void* d_workspace,
                        size_t workspace_bytes, void* stream) {
-  {   // argument checks that do not depend on the split (prepare validates cfg / w / shapes)
+  {   // validation of the whole call (and its workspace) before anything is enqueued
     Dims d{};
-    std::vector<LayerSaved> layers;
-    Saved sv{};
-    const size_t need = cfg ? sskd_teacher_workspace_bytes(cfg, B, S) : 0;
-    if (B > 0 && (!d_workspace || workspace_bytes < need))
-      return sskd::fail(SSKD_ERR_WORKSPACE, "teacher_score: workspace %zu B < required %zu B", workspace_bytes, need);
-    int rc = prepare(cfg, w, B, S, 0, d_workspace, need, &d, &layers, &sv);
+    int rc = check(cfg, w, B, S, &d);
     if (rc != SSKD_OK || B == 0) return rc;
+    const size_t need = sskd_teacher_workspace_bytes(cfg, B, S);
+    if (!d_workspace || workspace_bytes < need)
+      return sskd::fail(SSKD_ERR_WORKSPACE, "teacher_score: workspace %zu B < required %zu B", workspace_bytes, need);
   }
   SSKD_REQUIRE(d_head_dense_w && d_head_dense_b && d_head_out_w && d_head_out_b && d_ids && d_mask && d_logits,
                "teacher_score: null pointer");
   hipStream_t st = sskd::as_stream(stream);
-  int parts = sskd::forward_stream_parts() >= 2 ? 2 : 1;
+  const int parts = generic_parts(cfg, B, S, 0);
   const int Bp = B / 2;
-  const size_t part_bytes = (sskd_teacher_workspace_bytes(cfg, Bp, S) + 255) & ~(size_t)255;
-  if (!(B % 2 == 0 && ((int64_t)Bp * S) % 256 == 0 && (int64_t)Bp * S >= 16384 && 2 * part_bytes <= workspace_bytes)) parts = 1;
+  const size_t part_bytes = parts == 2 ? part_stride(cfg, B, S, 0) : 0;
   if (parts == 1)
     return teacher_score_rows(cfg, w, d_head_dense_w, d_head_dense_b, d_head_out_w, d_head_out_b, d_ids, d_mask, B, S,
                               d_logits, d_workspace, workspace_bytes, st);
