@@ -1377,7 +1377,7 @@ int run_layers(const sskd_encoder_config* cfg, const sskd_encoder_weights* w, co
                           (size_t)qa_tiles * ((nkt > 8 ? 2 : 4) * 128 * sizeof(bf16x8) + 32 * sizeof(float)) + 2 * 96 * sizeof(float);
     // all 12 heads per workgroup once there are enough batch rows to fill the chip; fewer heads
     // per workgroup (more workgroups) for small batches
-    qa.hpw = qa_rows >= 256 ? 12 : (qa_rows >= 64 ? 4 : 1);
+    qa.hpw = qa_rows >= 256 ? 12 : (qa_rows >= 64 ? 4 : 1);   // (12 stays best under the two-branch forward too: 6 / 4 / 3 heads measured -1.8 / -4 / -6 %)
     GemmN384Params o{};
     o.x = reinterpret_cast<const bf16x8*>(ws.ctx);
     o.w = static_cast<const bf16x8*>(lw.wo);

@@ -177,11 +177,12 @@ def test_short_sequences_packed_per_workgroup(enc_l2, S):
 def test_persistent_mlp_groups_match_one_group_per_workgroup(enc_l2):
     """The fused MLP is a persistent kernel: one workgroup per CU walks the 128-token groups blockIdx, blockIdx + gridDim,
     ... and its producers request the NEXT group's context rows while the consumers finish the current one
-    (csrc/encoder.hip fused_mlp_ln_kernel).  A 384 x 256 batch is 768 groups (three per workgroup on 256 CUs); the same rows
-    in slices of 64 are 128 groups (one per workgroup, nothing prefetched).  Rows are independent, so the two must agree
-    bit for bit - a context image that lands early or late shows up here."""
+    (csrc/encoder.hip fused_mlp_ln_kernel).  A 328 x 256 batch is 656 groups: on 256 CUs 144 workgroups walk three groups,
+    112 walk two (a ragged last round); the same rows in slices of 64 are at most 128 groups (one per workgroup, nothing
+    prefetched).  Rows are independent, so the two must agree bit for bit - a context image that lands early or late, or
+    a workgroup that prefetches past its last group, shows up here."""
     enc, cfg, sd = enc_l2
-    B, S = 384, 256
+    B, S = 328, 256
     rng = np.random.default_rng(31)
     lengths = [int(x) for x in rng.integers(2, S + 1, size=B)]
     for b in range(0, B, 7):
