@@ -29,8 +29,6 @@
 #include "common.h"
 
 #include <algorithm>
-#include <cstdlib>
-#include <mutex>
 #include <type_traits>
 #include <vector>
 
