@@ -457,7 +457,9 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
   // producers, idle while the consumers finish a group, request the NEXT group's context image under that tail.
   // The two roles never share code, not even the loop over groups: the producers' 96 registers of W1 fragments and the
   // consumers' 192 accumulators must not be live in one block, and a loop body without role branches is what the register
-  // allocator keeps spill-free.  Both branches execute the same workgroup barriers (3 + 2 MLP_SUPER + 3 per group).
+  // allocator keeps spill-free.  Both branches execute the same workgroup barriers per group: 2 inside the prologue, 1 that
+  // completes the image, 2 per super-chunk (the consumers run one super-chunk behind: their first two are bare, the producers'
+  // last two sit in their tail), 1 for the LayerNorm statistics.
   if (producer) {
     for (int grp = blockIdx.x; grp < p.n_groups; grp += gridDim.x) {
       // the lane id is re-derived per group through an opaque copy: otherwise every per-lane address of the body (a dozen
