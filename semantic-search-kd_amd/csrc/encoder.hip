@@ -481,25 +481,25 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
       __syncthreads();  // the X1 image is complete
       const int hp = pq;
       SSKD_STAMP(0, 60, 1);
-  #ifdef SSKD_PROBE
+#ifdef SSKD_PROBE
       if (blockIdx.x == 0 && pq == 0 && lane == 0) g_probe[0][60][0] = t_begin;
-  #endif
+#endif
       const __amdgpu_buffer_rsrc_t w1rs = weight_rsrc(p.w1);
       bf16x8 w[KSTEPS];
-  #pragma unroll
+#pragma unroll
       for (int s = 0; s < KSTEPS; ++s) w[s] = buffer_frag(w1rs, lane16, (unsigned)((hp * KSTEPS + s) * 1024));
       f32x4 bias[4];
-  #pragma unroll
+#pragma unroll
       for (int g = 0; g < 4; ++g) bias[g] = *reinterpret_cast<const f32x4*>(p.b1 + hp * 32 + 8 * g + 4 * h);
       bf16x8 fd[4];   // this wave's finished half of the previous super-chunk
-  #pragma unroll
+#pragma unroll
       for (int tt = 0; tt < 4; ++tt) fd[tt] = zero_bf8();
       const bf16x8* xl = &ximg[0][0][lane];
       // slot n = 4 s + tt of a burst multiplies fragment (tt, s) of the image
       constexpr int XR = SSKD_MLP_XR, NS = 4 * KSTEPS;
       auto xat = [](int n) { return ((n & 3) * KSTEPS + (n >> 2)) * 64; };
       bf16x8 xb[XR];
-  #pragma unroll
+#pragma unroll
       for (int i = 0; i < XR - 1; ++i) xb[i] = xl[xat(i)];
       SSKD_STAMP(0, 60, 2);
       for (int it = 0; it < MLP_SUPER; ++it) {   // the consumers run one iteration behind (their last one is peeled below)
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
           const unsigned wnext = (unsigned)(((it + 1 < MLP_SUPER ? it + 1 : it) * 4 + hp) * KSTEPS * 1024);
           __builtin_amdgcn_sched_barrier(0);
           __builtin_amdgcn_s_setprio(3);
-  #pragma unroll
+#pragma unroll
           for (int n = 0; n < NS; ++n) {
             const int s = n >> 2, tt = n & 3;
             if (n + XR - 1 < NS) xb[(n + XR - 1) % XR] = xl[xat(n + XR - 1)];
@@ -525,12 +525,12 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
         SSKD_STAMP(0, it, 2);
-  #pragma unroll
+#pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
-  #pragma unroll
+#pragma unroll
           for (int i = 0; i < 8; ++i) fd[tt][i] = (__bf16)gelu_erf(acc[tt][i] + bias[i >> 2][i & 3]);
           f32x4 r0, r1;
-  #pragma unroll
+#pragma unroll
           for (int e = 0; e < 4; ++e) {
             r0[e] = acc[tt][8 + e] + bias[2][e];
             r1[e] = acc[tt][12 + e] + bias[3][e];
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
           hraw[hp][tt][1][lane] = r1;
         }
         // pin the finished values here, or the compiler sinks their whole computation past the barrier into the burst
-  #pragma unroll
+#pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
           u32x4 t = __builtin_bit_cast(u32x4, fd[tt]);
           asm volatile("" : "+v"(t));
@@ -548,16 +548,16 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
         __builtin_amdgcn_sched_barrier(0);
         {   // the next super-chunk's bias and the ring's first fragments: both a whole phase ahead of their use
           const int nx = it + 1 < MLP_SUPER ? it + 1 : it;
-  #pragma unroll
+#pragma unroll
           for (int g = 0; g < 4; ++g) bias[g] = *reinterpret_cast<const f32x4*>(p.b1 + nx * 128 + hp * 32 + 8 * g + 4 * h);
-  #pragma unroll
+#pragma unroll
           for (int i = 0; i < XR - 1; ++i) xb[i] = xl[xat(i)];
         }
         __builtin_amdgcn_sched_barrier(0);
         SSKD_STAMP(0, it, 3);
         __syncthreads();
       }
-  #pragma unroll
+#pragma unroll
       for (int tt = 0; tt < 4; ++tt) hh[0][hp][tt][lane] = fd[tt];
       SSKD_STAMP(0, 60, 3);
       // nobody reads the X1 image any more (the consumers took the residual at their set-up): the next group's context rows
@@ -596,33 +596,33 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
       __syncthreads();  // the X1 image is complete
       const int fq = pq;
       SSKD_STAMP(1, 60, 1);
-  #ifdef SSKD_PROBE
+#ifdef SSKD_PROBE
       if (blockIdx.x == 0 && pq == 0 && lane == 0) g_probe[1][60][0] = t_begin;
-  #endif
+#endif
       // y starts as bias + residual (the image is X1): the epilogue is the LayerNorm alone
       f32x16 y[3][4];
       f32x4 bb[2][4];   // b2 of feature tile j, requested one tile ahead (one L2 round trip per tile, not per accumulator)
-  #pragma unroll
+#pragma unroll
       for (int g = 0; g < 4; ++g) bb[0][g] = *reinterpret_cast<const f32x4*>(p.b2 + fq * 96 + 8 * g + 4 * h);
-  #pragma unroll
+#pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int nt = fq * 3 + j;
         if (j + 1 < 3) {
-  #pragma unroll
+#pragma unroll
           for (int g = 0; g < 4; ++g) bb[(j + 1) & 1][g] = *reinterpret_cast<const f32x4*>(p.b2 + (nt + 1) * 32 + 8 * g + 4 * h);
         }
         __builtin_amdgcn_sched_barrier(0);
-  #pragma unroll
+#pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
           const __bf16* res = reinterpret_cast<const __bf16*>(&ximg[tt][0][0]);
-  #pragma unroll
+#pragma unroll
           for (int g = 0; g < 4; ++g) {
             const bf16x4 rr = *reinterpret_cast<const bf16x4*>(res + ((2 * nt + (g >> 1)) * 64 + r + 32 * (g & 1)) * 8 + 4 * h);
-  #pragma unroll
+#pragma unroll
             for (int e = 0; e < 4; ++e) y[j][tt][4 * g + e] = bb[j & 1][g][e] + bf2f(rr[e]);
           }
           __builtin_amdgcn_sched_barrier(0);   // one tile at a time: hoisted loads would spill the accumulators for good
-        }
+        }                                      // (reading the residual rows one tile ahead: measured neutral)
       }
       // Group order of this wave: position cs -> (hidden tile cc, k-step s2) = (cs + 2 fq + 1) mod 8, i.e. it starts with
       // the fragments (fq, 1) this wave wrote itself in phase 1.  Fragment f = 3 cs + j of super-chunk sc is
@@ -636,20 +636,20 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
       };
       constexpr int NF = 24;
       bf16x8 a[9];
-  #pragma unroll
+#pragma unroll
       for (int i = 0; i < 9; ++i) a[i] = frag_ld(0, i);
       __syncthreads();   // iteration 0: nothing to consume yet
       __syncthreads();
       for (int it = 1; it <= MLP_SUPER; ++it) {
         SSKD_STAMP(1, it, 0);
         // phase 1: GELU of this wave's share (hidden tile fq, k-step 1) of the previous super-chunk's raw half
-  #pragma unroll
+#pragma unroll
         for (int tt = 0; tt < 4; ++tt) {   // four values at a time: 192 accumulators leave ~25 registers for this
           bf16x8 f;
-  #pragma unroll
+#pragma unroll
           for (int hf = 0; hf < 2; ++hf) {
             const f32x4 rw = hraw[fq][tt][hf][lane];
-  #pragma unroll
+#pragma unroll
             for (int e = 0; e < 4; ++e) f[4 * hf + e] = (__bf16)gelu_erf(rw[e]);
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
           return ((csr & 1) * 16 + (csr >> 1) * 4 + tt) * 64;
         };
         bf16x8 hb[HR];
-  #pragma unroll
+#pragma unroll
         for (int i = 0; i < HR - 1; ++i) hb[i] = hl[hidx(i)];   // own fragments (same wave: ordered behind the writes above)
         __builtin_amdgcn_sched_barrier(0);
         SSKD_STAMP(1, it, 3);
@@ -676,23 +676,23 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
           const int scn = sc + 1 < MLP_SUPER ? sc + 1 : sc;
           __builtin_amdgcn_s_setprio(3);
           __builtin_amdgcn_sched_barrier(0);
-  #pragma unroll
+#pragma unroll
           for (int g = 0; g < 32; ++g) {
             const int cs = g >> 2, tt = g & 3;
             if (g + HR - 1 < 32) hb[(g + HR - 1) % HR] = hl[hidx(g + HR - 1)];
-  #pragma unroll
+#pragma unroll
             for (int j = 0; j < 3; ++j)
               y[j][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(cs * 3 + j) % 9], hb[g % HR], y[j][tt], 0, 0, 0);
             if (tt == 3) {   // the group is finished: refill its registers (f + 9 < 24: this super-chunk's fragment f + 9;
                              // f + 9 >= 27: the next one's fragment f - 18)
-  #pragma unroll
+#pragma unroll
               for (int j = 0; j < 3; ++j) {
                 const int f = cs * 3 + j, fn = f + 9;
                 if (fn < NF) a[f % 9] = frag_ld(sc, fn);
                 else if (fn >= 27) a[f % 9] = frag_ld(scn, fn - 27);
               }
               if (cs == 7) {   // the pad: fragments 6 .. 8 of the next super-chunk
-  #pragma unroll
+#pragma unroll
                 for (int j = 6; j < 9; ++j) a[j] = frag_ld(scn, j);
               }
             }
@@ -706,12 +706,12 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
       // epilogue: LayerNorm over the token's 384 features - 48 in this lane, 48 in lane ^ 32, 96 per consumer
       SSKD_STAMP(1, 60, 3);
       float2* const stats = reinterpret_cast<float2*>(&hraw[0][0][0][0]);   // dead by now: [128 tokens][4 consumers]
-  #pragma unroll
+#pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
         float sum = 0.f, sq = 0.f;
-  #pragma unroll
+#pragma unroll
         for (int j = 0; j < 3; ++j)
-  #pragma unroll
+#pragma unroll
           for (int i = 0; i < 16; ++i) {
             sum += y[j][tt][i];
             sq = fmaf(y[j][tt][i], y[j][tt][i], sq);
@@ -722,10 +722,10 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
       }
       __syncthreads();
       float mean[4], rstd[4];
-  #pragma unroll
+#pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
         float sum = 0.f, sq = 0.f;
-  #pragma unroll
+#pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float2 t = stats[(tt * 32 + r) * 4 + k];
           sum += t.x;
@@ -735,21 +735,21 @@ __global__ __launch_bounds__(512) void fused_mlp_ln_kernel(MlpParams p) {
         const float var = fmaxf(sq * (1.0f / H) - mean[tt] * mean[tt], 0.f);
         rstd[tt] = rsqrtf(var + p.eps);
       }
-  #pragma unroll
+#pragma unroll
       for (int j = 0; j < 3; ++j) {   // feature tile outermost: gamma / beta are fetched once per tile, not once per token tile
         const int nt = fq * 3 + j;
         f32x4 ga[4], be[4];
-  #pragma unroll
+#pragma unroll
         for (int g = 0; g < 4; ++g) {
           ga[g] = *reinterpret_cast<const f32x4*>(p.gamma + nt * 32 + 8 * g + 4 * h);
           be[g] = *reinterpret_cast<const f32x4*>(p.beta + nt * 32 + 8 * g + 4 * h);
         }
-  #pragma unroll
+#pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
           f32x4 v[4];
-  #pragma unroll
+#pragma unroll
           for (int g = 0; g < 4; ++g)
-  #pragma unroll
+#pragma unroll
             for (int e = 0; e < 4; ++e) v[g][e] = (y[j][tt][4 * g + e] - mean[tt]) * rstd[tt] * ga[g][e] + be[g][e];
           store_tile_frag(p.out + frag_base(tile0 + tt, 2 * nt, KSTEPS) * 8, v, lane);
         }
