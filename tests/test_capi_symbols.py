@@ -35,6 +35,28 @@ def test_abi_version_and_pure_host_queries(native_lib):
     assert native_lib.sskd_index_search_workspace_bytes(1_000_000, 10_000, 10) > 0
 
 
+def test_generic_workspace_covers_the_two_branch_split(native_lib):
+    """sskd_generic_forward / _backward / sskd_teacher_score cut batches of >= 2 x 16 384 tokens into two halves on two streams,
+    each half carving its own workspace out of the caller's buffer (csrc/train.hip generic_parts: one rule on (cfg, B, S,
+    training), so forward and backward agree).  The size query must cover both halves - and must not charge small batches."""
+    import ctypes as C
+
+    from semantic_search_kd_amd import _native
+
+    cfg = _native.GenericConfig(vocab_size=30522, hidden=384, layers=12, heads=12, intermediate=1536, max_positions=512,
+                                type_vocab=2, layer_norm_eps=1e-12, pos_offset=0)
+    ws = lambda B, S, tr: int(native_lib.sskd_generic_workspace_bytes(C.byref(cfg), B, S, tr))
+    for tr in (0, 1):
+        whole, half = ws(256, 256, tr), ws(128, 256, tr)         # 2 x 32 768 tokens: split
+        assert half > 0 and whole >= 2 * half
+        assert ws(128, 256, tr) >= 2 * ws(64, 256, tr)           # 2 x 16 384 tokens: the smallest batch that splits
+        small, smaller = ws(64, 256, tr), ws(32, 256, tr)        # 2 x 8 192 tokens: one part, sized as before
+        assert smaller < small < 2 * smaller + 4096 * 64
+        assert ws(3, 64, tr) > 0 and ws(0, 256, tr) == 0
+    t = lambda B, S: int(native_lib.sskd_teacher_workspace_bytes(C.byref(cfg), B, S))
+    assert t(128, 256) == ws(128, 256, 0)
+
+
 def test_search_plan_reports_geometry(native_lib):
     import ctypes as C
 
