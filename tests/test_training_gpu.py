@@ -412,3 +412,39 @@ def test_fused_backward_refuses_hooks_and_frozen_parameters(gpu):
     w.requires_grad_(False)
     with pytest.raises(NotImplementedError, match="requires_grad"):
         model(ids, mask)
+
+
+@pytest.mark.gpu
+def test_two_branch_backward_equals_the_sum_of_its_halves(gpu):
+    """sskd_generic_forward / _backward run batches of >= 2 x 16 384 tokens as two halves on two streams (csrc/train.hip
+    generic_parts); the halves add into the SAME gradient buffers (atomic accumulation).  128 x 256 tokens split; the two
+    64-row halves, called one after the other, do not.  Embeddings must agree bit for bit (rows do not interact), the
+    gradient of the whole batch must equal the sum of the halves' gradients up to the order of fp32 additions."""
+    from semantic_search_kd_amd.training import TrainableEncoder
+
+    cfg = BertConfig(vocab_size=2000, num_hidden_layers=2)     # the e5-small-v2 widths: every weight gradient on gemm_tn384
+    sd = synthetic_state_dict(cfg)
+    B, S = 128, 256
+    rng = np.random.default_rng(17)
+    lengths = [int(x) for x in rng.integers(4, S + 1, size=B)]
+    lengths[0] = lengths[64] = S
+    ids, mask = enc_oracle.synthetic_token_ids(B, S, seed=41, vocab=2000, lengths=lengths)
+    probe = torch.from_numpy(rng.standard_normal((B, cfg.hidden_size)).astype(np.float32)).cuda()
+
+    def grads(rows):
+        model = TrainableEncoder(cfg, sd, "cuda:0")
+        embs = []
+        for lo, hi in rows:
+            emb = model(ids[lo:hi], mask[lo:hi], normalize=True)
+            (emb * probe[lo:hi]).sum().backward()
+            embs.append(emb.detach().clone())
+        return torch.cat(embs), {n: model.p(n).grad.detach().clone() for n in model.names}
+
+    e_whole, g_whole = grads([(0, B)])
+    e_halves, g_halves = grads([(0, B // 2), (B // 2, B)])
+    assert torch.equal(e_whole, e_halves)
+    top = max(float(v.abs().max()) for v in g_halves.values())
+    for name, ref in g_halves.items():
+        got = g_whole[name]
+        assert torch.isfinite(got).all(), name
+        assert float((got - ref).abs().max()) <= 2e-3 * max(float(ref.abs().max()), 1e-3 * top), name
